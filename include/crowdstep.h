@@ -1,0 +1,251 @@
+/*
+ * crowdstep.h — C ABI of the MI355X-native crowd-step engine.
+ *
+ * This is the drop-in boundary for the `Simulation::step` hot path of
+ * open-rmf/rmf_crowdsim.  The reference exposes a Rust trait/struct API and no
+ * FFI of its own, so every entry point below names the reference item it
+ * replaces (paths relative to the reference tree, rmf_crowdsim/src/...).
+ * A Rust host keeps its `Simulation` / `HighLevelPlanner` / `LocalPlanner` /
+ * `EventListener` surface and forwards to these symbols through `extern "C"`
+ * (binding sketch: INTEGRATION.md).
+ *
+ * Two shared libraries implement this header:
+ *   - rmf_crowdsim_amd/lib/libcrowdstep_hip.so  : the product (HIP kernels, gfx950)
+ *   - oracle/_build/libcrowdstep_oracle.so      : TEST ORACLE ONLY (f64 CPU restatement)
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; the engine owns all device
+ *     memory, the caller owns every buffer it passes in.
+ *   - `int` results: 0 = Ok, non-zero = Err; `cs_last_error` then carries the
+ *     reference's error string ("Index out of bounds",
+ *     "Failed to add agents from source").
+ *   - one engine = one caller thread at a time (mirrors `&mut self`, lib.rs:195).
+ *   - positions/velocities cross the ABI as f64 (the reference's `Vec2f`,
+ *     lib.rs:40-43); the device state is f32 cell-relative.
+ *   - agent ids cross as u64 (`AgentId = usize`, lib.rs:36).
+ */
+#ifndef CROWDSTEP_H
+#define CROWDSTEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+
+typedef struct cs_engine cs_engine;
+
+/* LocationHash2D::new(width, height, cell_size, offset)
+ * spatial_index/location_hash_2d.rs:33-51 */
+typedef struct cs_grid_desc {
+  double width;
+  double height;
+  double cell_size;
+  double offset_x;
+  double offset_y;
+} cs_grid_desc;
+
+/* Device placement.  A tile engine owns the cell columns/rows
+ * [tile_cx0, tile_cx1) x [tile_cy0, tile_cy1) of the global grid and keeps a
+ * ghost ring for neighbour queries (multi-GPU, DESIGN.md "Tiles").
+ * All-zero tile bounds = the engine owns the whole grid. */
+typedef struct cs_device_cfg {
+  int32_t device_ordinal;   /* HIP device index for this engine               */
+  uint32_t flags;           /* CS_CFG_* bits                                  */
+  uint32_t tile_cx0, tile_cx1, tile_cy0, tile_cy1;
+  uint64_t capacity_hint;   /* expected max agents (0 = grow on demand)       */
+  void* stream;             /* hipStream_t to run on (NULL = engine's own)    */
+} cs_device_cfg;
+
+#define CS_CFG_DEFAULT 0u
+#define CS_CFG_FORCE_GATHER 1u  /* use the direct-gather neighbour kernel only */
+#define CS_CFG_FORCE_TILED 2u   /* use the LDS-tiled neighbour kernel only     */
+
+/* Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
+ *               agent_mass, agent_radius)   local_planners/zanlungo.rs:31-48 */
+typedef struct cs_zanlungo_params {
+  double agent_scale;
+  double obstacle_scale; /* stored, never read by the reference */
+  double reaction_time;  /* stored, never read by the reference */
+  double force_distance;
+  double agent_mass;
+  double agent_radius;
+} cs_zanlungo_params;
+
+/* HighLevelPlanner (highlevel_planners/highlevel_planners.rs:8-16).
+ * Trait objects cannot run on the device, so planners are registered as data:
+ *   NONE      get_desired_velocity returns None      (lib.rs:263-273: vel = 0)
+ *   CONSTANT  Some(v)            (StubHighLevelPlan, lib.rs:391-420)
+ *   ID_PARITY even id -> Some(-v), odd id -> Some(v)
+ *             (rmf_crowdsim_viz/src/main.rs:20-30)
+ *   CALLBACK  host trait object, evaluated per step for the whole batch       */
+enum {
+  CS_HLP_NONE = 0,
+  CS_HLP_CONSTANT = 1,
+  CS_HLP_ID_PARITY = 2,
+  CS_HLP_CALLBACK = 3
+};
+
+/* get_desired_velocity(&mut self, &Agent, Duration) -> Option<Vec2f> for n
+ * agents at once.  `time_s` is always 0 (the reference never advances
+ * sim_time, lib.rs:81,110,268).  out_some[i]=0 means None. */
+typedef void (*cs_hlp_velocity_fn)(void* user, size_t n, const uint64_t* ids,
+                                   const double* pos_xy, const double* vel_xy,
+                                   double time_s, double* out_vel_xy,
+                                   uint8_t* out_some);
+/* set_target(&mut self, &Agent, point, tolerance)  highlevel_planners.rs:12 */
+typedef void (*cs_hlp_set_target_fn)(void* user, uint64_t id, double pos_x,
+                                     double pos_y, double point_x,
+                                     double point_y, double tol_x, double tol_y);
+/* remove_agent_id(&mut self, AgentId)              highlevel_planners.rs:15 */
+typedef void (*cs_hlp_remove_fn)(void* user, uint64_t id);
+
+typedef struct cs_hlp_desc {
+  uint32_t kind; /* CS_HLP_* */
+  double vx, vy; /* CONSTANT / ID_PARITY */
+  cs_hlp_velocity_fn velocity; /* CALLBACK */
+  cs_hlp_set_target_fn set_target;
+  cs_hlp_remove_fn remove_agent;
+  void* user;
+} cs_hlp_desc;
+
+/* CrowdGenerator::get_number_to_spawn(&self, Duration) -> usize
+ * source_sink/source_sink.rs:30-33.
+ *   MONOTONIC       round(dt * rate)                     source_sink.rs:96-100
+ *   POISSON_SEEDED  Poisson(dt * rate) drawn from a counter-based generator
+ *                   keyed by (seed, step index); replaces PoissonCrowd
+ *                   (source_sink.rs:75-82), whose thread_rng is unseedable
+ *   CALLBACK        host trait object                                        */
+enum { CS_GEN_MONOTONIC = 0, CS_GEN_POISSON_SEEDED = 1, CS_GEN_CALLBACK = 2 };
+typedef size_t (*cs_generator_fn)(void* user, double dt_seconds);
+
+/* struct SourceSink                              source_sink/source_sink.rs:36-60 */
+typedef struct cs_source_sink_desc {
+  double source_x, source_y;
+  double radius_sink;
+  uint32_t generator_kind; /* CS_GEN_* */
+  double rate;
+  uint64_t seed;
+  cs_generator_fn generator;
+  void* generator_user;
+  uint32_t hlp; /* handle from cs_register_hlp */
+  uint32_t lp;  /* handle from cs_register_zanlungo / _no_local_plan */
+  const double* waypoints_xy; /* n_waypoints pairs; last one is the sink */
+  size_t n_waypoints;
+  int32_t loop_forever;
+  double agent_eyesight_range;
+} cs_source_sink_desc;
+
+/* What one step did (the reference prints or drops these). */
+typedef struct cs_step_report {
+  uint64_t n_agents;        /* alive after the step                            */
+  uint64_t n_spawned;       /* lib.rs:199-254                                  */
+  uint64_t n_destroyed;     /* lib.rs:378-380                                  */
+  uint64_t n_waypoint_hits; /* "Reached waypoint", lib.rs:317                  */
+  uint64_t n_tti_zero;      /* agents whose min time-to-collision was 0        */
+  uint64_t n_nonfinite;     /* agents whose new state is NaN/inf               */
+  uint64_t n_clamped;       /* agents binned by the saturating cast (a4)       */
+} cs_step_report;
+
+/* EventListener callbacks, queued during cs_step and drained afterwards
+ * lib.rs:22-33,151-153,189-191 */
+enum { CS_EVENT_SPAWNED = 1, CS_EVENT_DESTROYED = 2 };
+typedef struct cs_event {
+  uint32_t kind;
+  uint32_t source_sink; /* owner handle or UINT32_MAX */
+  uint64_t id;
+  double x, y; /* spawn position (SPAWNED only) */
+} cs_event;
+
+/* pub struct Agent, lib.rs:46-65 (fields a caller can observe) */
+typedef struct cs_agent_view {
+  uint64_t id;
+  double x, y;
+  double vx, vy;
+  uint64_t next_waypoint;
+  double eyesight_range;
+} cs_agent_view;
+
+/* ---- lifetime ---------------------------------------------------------- */
+uint32_t cs_abi_version(void);
+/* Simulation::new(LocationHash2D::new(..))   lib.rs:103, location_hash_2d.rs:33 */
+cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg);
+void cs_destroy(cs_engine*);
+const char* cs_last_error(const cs_engine*);
+/* "hip:<gcnArchName>" for the product, "oracle:f64" for the test oracle */
+const char* cs_backend_name(const cs_engine*);
+
+/* ---- planners as data -------------------------------------------------- */
+uint32_t cs_register_zanlungo(cs_engine*, const cs_zanlungo_params*); /* zanlungo.rs:31 */
+uint32_t cs_register_no_local_plan(cs_engine*);           /* no_local_plan.rs:7-18 */
+uint32_t cs_register_hlp(cs_engine*, const cs_hlp_desc*); /* highlevel_planners.rs:8 */
+
+/* ---- population -------------------------------------------------------- */
+/* Simulation::add_agents                                        lib.rs:119-156 */
+int cs_add_agents(cs_engine*, const double* xy, size_t n, uint32_t hlp,
+                  uint32_t lp, double eyesight, uint64_t* out_ids);
+/* Simulation::remove_agents (unknown id: returns Err instead of panicking)
+ *                                                               lib.rs:176-192 */
+int cs_remove_agent(cs_engine*, uint64_t id);
+/* Simulation::add_source_sink / remove_source_sink              lib.rs:159-168 */
+uint32_t cs_add_source_sink(cs_engine*, const cs_source_sink_desc*);
+void cs_remove_source_sink(cs_engine*, uint32_t handle);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Simulation::step(dur), dt_seconds = dur.as_secs_f64()          lib.rs:195-383
+ * report may be NULL (then the call does not wait for the device unless
+ * source-sinks or callback planners need the host). */
+int cs_step(cs_engine*, double dt_seconds, cs_step_report* report);
+/* Wait until every queued step has finished on the device. */
+int cs_synchronize(cs_engine*);
+
+/* ---- observation ------------------------------------------------------- */
+size_t cs_agent_count(cs_engine*);                       /* agents.len(), lib.rs:71 */
+/* `pub agents` view, ascending id; returns number written       lib.rs:71    */
+size_t cs_read_agents(cs_engine*, cs_agent_view* out, size_t cap);
+size_t cs_drain_events(cs_engine*, cs_event* out, size_t cap);
+/* SpatialIndex::get_neighbours_in_radius                location_hash_2d.rs:240-258
+ * returns the full count; writes min(count, cap) ids in reference cell order
+ * (x-major, y-minor) with ascending id inside a cell. */
+size_t cs_query_radius(cs_engine*, double radius, double x, double y,
+                       uint64_t* out_ids, size_t cap);
+/* SpatialIndex::get_nearest_neighbours                  location_hash_2d.rs:151-238 */
+size_t cs_query_knn(cs_engine*, size_t k, double x, double y, uint64_t* out_ids);
+
+/* ---- measurement (bench.py / rocprof cross-check) ---------------------- */
+/* Kernel names the engine launches per step, for HIP-event timing. */
+enum {
+  CS_K_NEIGHBOUR_FORCE = 0, /* Zanlungo neighbour pass + integrate (K4)  */
+  CS_K_SCAN = 1,            /* exclusive scan of cell counts (K2)        */
+  CS_K_SCATTER = 2,         /* reorder into cell order (K3)              */
+  CS_K_SPAWN = 3,           /* source occupancy + append (K6)            */
+  CS_K_HALO = 4,            /* halo pack/unpack (K7)                     */
+  CS_K_COUNT = 5
+};
+/* Turn per-kernel hipEvent timing on/off (events are recorded on the engine's
+ * stream around each launch). */
+void cs_profile_enable(cs_engine*, int on);
+/* Sum of durations (ms) and launch count since the last reset. */
+int cs_profile_read(cs_engine*, uint32_t kernel, double* total_ms, uint64_t* launches);
+void cs_profile_reset(cs_engine*);
+
+/* ---- tiles: halo exchange hooks (multi-GPU, one engine per rank) -------- */
+/* Directions of the two-phase exchange: X first, then Y (corners forward). */
+enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3 };
+#define CS_HALO_RECORD_BYTES 32u
+/* Caller-provided device buffers (e.g. torch CUDA tensors): capacity in records.
+ * Word 0 of each buffer is the record count header. */
+int cs_halo_set_buffers(cs_engine*, uint32_t dir, void* send_dev, void* recv_dev,
+                        uint64_t capacity_records);
+/* Pack border + migrating agents for one axis (0 = X pair, 1 = Y pair). */
+int cs_halo_pack(cs_engine*, uint32_t axis);
+/* Merge what arrived on one axis into the unsorted tail of the tile. */
+int cs_halo_unpack(cs_engine*, uint32_t axis);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROWDSTEP_H */

@@ -1,0 +1,130 @@
+"""ctypes declarations of include/crowdstep.h (the C-ABI boundary).
+
+Declarations only: structs, callback types and `bind(lib)` which attaches
+argument/return types to a loaded shared library.  No compute lives here.
+"""
+import ctypes as C
+
+CS_ABI_VERSION = 1
+
+CS_CFG_DEFAULT = 0
+CS_CFG_FORCE_GATHER = 1
+CS_CFG_FORCE_TILED = 2
+
+CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK = 0, 1, 2, 3
+CS_GEN_MONOTONIC, CS_GEN_POISSON_SEEDED, CS_GEN_CALLBACK = 0, 1, 2
+CS_EVENT_SPAWNED, CS_EVENT_DESTROYED = 1, 2
+(CS_K_NEIGHBOUR_FORCE, CS_K_SCAN, CS_K_SCATTER, CS_K_SPAWN, CS_K_HALO, CS_K_COUNT) = range(6)
+KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo"]
+CS_DIR_XLO, CS_DIR_XHI, CS_DIR_YLO, CS_DIR_YHI = 0, 1, 2, 3
+CS_HALO_RECORD_BYTES = 32
+NO_SOURCE_SINK = 0xFFFFFFFF
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("width", C.c_double), ("height", C.c_double), ("cell_size", C.c_double),
+                ("offset_x", C.c_double), ("offset_y", C.c_double)]
+
+
+class DeviceCfg(C.Structure):
+    _fields_ = [("device_ordinal", C.c_int32), ("flags", C.c_uint32),
+                ("tile_cx0", C.c_uint32), ("tile_cx1", C.c_uint32),
+                ("tile_cy0", C.c_uint32), ("tile_cy1", C.c_uint32),
+                ("capacity_hint", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class ZanlungoParams(C.Structure):
+    _fields_ = [("agent_scale", C.c_double), ("obstacle_scale", C.c_double),
+                ("reaction_time", C.c_double), ("force_distance", C.c_double),
+                ("agent_mass", C.c_double), ("agent_radius", C.c_double)]
+
+
+HlpVelocityFn = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                            C.POINTER(C.c_double), C.POINTER(C.c_uint8))
+HlpSetTargetFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                             C.c_double, C.c_double, C.c_double)
+HlpRemoveFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)
+GeneratorFn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_double)
+
+
+class HlpDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("vx", C.c_double), ("vy", C.c_double),
+                ("velocity", HlpVelocityFn), ("set_target", HlpSetTargetFn),
+                ("remove_agent", HlpRemoveFn), ("user", C.c_void_p)]
+
+
+class SourceSinkDesc(C.Structure):
+    _fields_ = [("source_x", C.c_double), ("source_y", C.c_double), ("radius_sink", C.c_double),
+                ("generator_kind", C.c_uint32), ("rate", C.c_double), ("seed", C.c_uint64),
+                ("generator", GeneratorFn), ("generator_user", C.c_void_p),
+                ("hlp", C.c_uint32), ("lp", C.c_uint32),
+                ("waypoints_xy", C.POINTER(C.c_double)), ("n_waypoints", C.c_size_t),
+                ("loop_forever", C.c_int32), ("agent_eyesight_range", C.c_double)]
+
+
+class StepReport(C.Structure):
+    _fields_ = [("n_agents", C.c_uint64), ("n_spawned", C.c_uint64), ("n_destroyed", C.c_uint64),
+                ("n_waypoint_hits", C.c_uint64), ("n_tti_zero", C.c_uint64),
+                ("n_nonfinite", C.c_uint64), ("n_clamped", C.c_uint64)]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+class Event(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("source_sink", C.c_uint32), ("id", C.c_uint64),
+                ("x", C.c_double), ("y", C.c_double)]
+
+
+class AgentView(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("x", C.c_double), ("y", C.c_double),
+                ("vx", C.c_double), ("vy", C.c_double), ("next_waypoint", C.c_uint64),
+                ("eyesight_range", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/crowdstep.h declares.
+SYMBOLS = {
+    "cs_abi_version": (C.c_uint32, []),
+    "cs_create": (C.c_void_p, [C.POINTER(GridDesc), C.POINTER(DeviceCfg)]),
+    "cs_destroy": (None, [C.c_void_p]),
+    "cs_last_error": (C.c_char_p, [C.c_void_p]),
+    "cs_backend_name": (C.c_char_p, [C.c_void_p]),
+    "cs_register_zanlungo": (C.c_uint32, [C.c_void_p, C.POINTER(ZanlungoParams)]),
+    "cs_register_no_local_plan": (C.c_uint32, [C.c_void_p]),
+    "cs_register_hlp": (C.c_uint32, [C.c_void_p, C.POINTER(HlpDesc)]),
+    "cs_add_agents": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint32,
+                                C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]),
+    "cs_remove_agent": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cs_add_source_sink": (C.c_uint32, [C.c_void_p, C.POINTER(SourceSinkDesc)]),
+    "cs_remove_source_sink": (None, [C.c_void_p, C.c_uint32]),
+    "cs_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
+    "cs_synchronize": (C.c_int, [C.c_void_p]),
+    "cs_agent_count": (C.c_size_t, [C.c_void_p]),
+    "cs_read_agents": (C.c_size_t, [C.c_void_p, C.POINTER(AgentView), C.c_size_t]),
+    "cs_drain_events": (C.c_size_t, [C.c_void_p, C.POINTER(Event), C.c_size_t]),
+    "cs_query_radius": (C.c_size_t, [C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                     C.POINTER(C.c_uint64), C.c_size_t]),
+    "cs_query_knn": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_double, C.c_double,
+                                  C.POINTER(C.c_uint64)]),
+    "cs_profile_enable": (None, [C.c_void_p, C.c_int]),
+    "cs_profile_read": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_uint64)]),
+    "cs_profile_reset": (None, [C.c_void_p]),
+    "cs_halo_set_buffers": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_uint64]),
+    "cs_halo_pack": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "cs_halo_unpack": (C.c_int, [C.c_void_p, C.c_uint32]),
+}
+
+
+def bind(lib):
+    """Attach restype/argtypes for every ABI symbol; raises AttributeError if one is missing."""
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    version = lib.cs_abi_version()
+    if version != CS_ABI_VERSION:
+        raise RuntimeError(f"crowdstep ABI mismatch: library {version}, bindings {CS_ABI_VERSION}")
+    return lib

@@ -1,0 +1,447 @@
+"""Host-side mirror of the reference's trait surface for the `Simulation::step` path.
+
+Same names and argument meaning as rmf_crowdsim (paths relative to
+rmf_crowdsim/src in the reference tree):
+
+    Simulation            lib.rs:69-383      new / add_agents / add_source_sink /
+                                             remove_source_sink / add_event_listener /
+                                             remove_agents / step / agents
+    EventListener         lib.rs:22-33
+    Agent                 lib.rs:46-65
+    HighLevelPlanner      highlevel_planners/highlevel_planners.rs:8-16
+    LocalPlanner          local_planners/local_planner.rs:7-18
+    Zanlungo / NoLocalPlan  local_planners/zanlungo.rs:31-48, no_local_plan.rs:7-18
+    LocationHash2D        spatial_index/location_hash_2d.rs:33-51
+    SourceSink / CrowdGenerator / MonotonicCrowd   source_sink/source_sink.rs:30-101
+
+Everything forwards to the C ABI (include/crowdstep.h) of the HIP engine; Rust
+`Result<_, String>` becomes `CrowdSimError(message)`.
+"""
+import ctypes as C
+import datetime
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi, _native
+
+
+class CrowdSimError(RuntimeError):
+    """`Err(String)` of the reference API ("Index out of bounds", ...)."""
+
+
+@dataclass
+class Agent:
+    """pub struct Agent, lib.rs:46-65 (the fields `step` maintains)."""
+    agent_id: int
+    position: np.ndarray
+    velocity: np.ndarray
+    next_waypoint: int
+    eyesight_range: float
+    orientation: float = 0.0   # never written after creation (lib.rs:138)
+    angular_vel: float = 0.0   # never written after creation (lib.rs:141)
+
+
+# ---- spatial index ---------------------------------------------------------
+class LocationHash2D:
+    """LocationHash2D::new(width, height, cell_size, offset); location_hash_2d.rs:33."""
+
+    def __init__(self, width, height, cell_size, offset):
+        self.width = float(width)
+        self.height = float(height)
+        self.cell_size = float(cell_size)
+        self.offset = (float(offset[0]), float(offset[1]))
+
+    def _desc(self):
+        return _abi.GridDesc(self.width, self.height, self.cell_size, *self.offset)
+
+
+# ---- local planners --------------------------------------------------------
+class LocalPlanner:
+    """trait LocalPlanner, local_planner.rs:7-18.  Only the two planners the
+    reference ships can run on the device; they are passed as data."""
+
+    def _register(self, lib, engine):
+        raise CrowdSimError("only Zanlungo and NoLocalPlan are device-evaluable local planners")
+
+
+class NoLocalPlan(LocalPlanner):
+    """no_local_plan.rs:7-18: returns the recommended velocity unchanged."""
+
+    def _register(self, lib, engine):
+        return lib.cs_register_no_local_plan(engine)
+
+
+class Zanlungo(LocalPlanner):
+    """Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
+    agent_mass, agent_radius); zanlungo.rs:31-48."""
+
+    def __init__(self, agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass,
+                 agent_radius):
+        self.params = _abi.ZanlungoParams(agent_scale, obstacle_scale, reaction_time,
+                                          force_distance, agent_mass, agent_radius)
+
+    def _register(self, lib, engine):
+        return lib.cs_register_zanlungo(engine, C.byref(self.params))
+
+
+# ---- high-level planners ---------------------------------------------------
+class HighLevelPlanner:
+    """trait HighLevelPlanner, highlevel_planners.rs:8-16.
+
+    Subclass and override `get_desired_velocity` for a host planner (evaluated
+    through the batched callback each step: the slow path), or use the data
+    planners below, which the device evaluates itself.
+    """
+
+    def get_desired_velocity(self, agent, time):
+        """-> (vx, vy) or None"""
+        return None
+
+    def set_target(self, agent, point, tolerance):
+        pass
+
+    def remove_agent_id(self, agent_id):
+        pass
+
+    # -- ABI plumbing --
+    def _desc(self):
+        keep = []
+
+        def velocity(_user, n, ids, pos, vel, time_s, out, some):
+            for i in range(n):
+                agent = Agent(int(ids[i]), np.array([pos[2 * i], pos[2 * i + 1]]),
+                              np.array([vel[2 * i], vel[2 * i + 1]]), 0, 0.0)
+                res = self.get_desired_velocity(agent, datetime.timedelta(seconds=time_s))
+                if res is None:
+                    some[i] = 0
+                else:
+                    some[i] = 1
+                    out[2 * i], out[2 * i + 1] = float(res[0]), float(res[1])
+
+        def set_target(_user, aid, px, py, tx, ty, tolx, toly):
+            agent = Agent(int(aid), np.array([px, py]), np.zeros(2), 0, 0.0)
+            self.set_target(agent, np.array([tx, ty]), np.array([tolx, toly]))
+
+        def remove(_user, aid):
+            self.remove_agent_id(int(aid))
+
+        fv, fs, fr = _abi.HlpVelocityFn(velocity), _abi.HlpSetTargetFn(set_target), \
+            _abi.HlpRemoveFn(remove)
+        keep += [fv, fs, fr]
+        return _abi.HlpDesc(_abi.CS_HLP_CALLBACK, 0.0, 0.0, fv, fs, fr, None), keep
+
+    def _register(self, lib, engine):
+        desc, keep = self._desc()
+        self._keepalive = keep
+        return lib.cs_register_hlp(engine, C.byref(desc))
+
+
+class _DataPlan(HighLevelPlanner):
+    _kind = _abi.CS_HLP_NONE
+
+    def __init__(self, default_vel=(0.0, 0.0)):
+        self.default_vel = (float(default_vel[0]), float(default_vel[1]))
+
+    def _desc(self):
+        return _abi.HlpDesc(self._kind, self.default_vel[0], self.default_vel[1],
+                            _abi.HlpVelocityFn(), _abi.HlpSetTargetFn(), _abi.HlpRemoveFn(),
+                            None), []
+
+
+class NoHighLevelPlan(_DataPlan):
+    """get_desired_velocity -> None for every agent (lib.rs:263-273 leaves vel = 0)."""
+    _kind = _abi.CS_HLP_NONE
+
+
+class StubHighLevelPlan(_DataPlan):
+    """The reference tests' stub: Some(default_vel) for every agent (lib.rs:391-420)."""
+    _kind = _abi.CS_HLP_CONSTANT
+
+    def get_desired_velocity(self, agent, time):
+        return self.default_vel
+
+
+class IdParityHighLevelPlan(_DataPlan):
+    """The visualiser's stub: even ids get -default_vel, odd ids +default_vel
+    (rmf_crowdsim_viz/src/main.rs:20-30)."""
+    _kind = _abi.CS_HLP_ID_PARITY
+
+    def get_desired_velocity(self, agent, time):
+        s = -1.0 if agent.agent_id % 2 == 0 else 1.0
+        return (s * self.default_vel[0], s * self.default_vel[1])
+
+
+# ---- source / sink ---------------------------------------------------------
+class CrowdGenerator:
+    """trait CrowdGenerator, source_sink.rs:30-33."""
+
+    def get_number_to_spawn(self, time_elapsed):
+        return 0
+
+    def _fill(self, desc):
+        def gen(_user, dt):
+            return int(self.get_number_to_spawn(datetime.timedelta(seconds=dt)))
+        fn = _abi.GeneratorFn(gen)
+        desc.generator_kind = _abi.CS_GEN_CALLBACK
+        desc.generator = fn
+        return [fn]
+
+
+class MonotonicCrowd(CrowdGenerator):
+    """MonotonicCrowd::new(rate): round(dt * rate) per step; source_sink.rs:85-101."""
+
+    def __init__(self, rate):
+        self.rate = float(rate)
+
+    def get_number_to_spawn(self, time_elapsed):
+        v = time_elapsed.total_seconds() * self.rate
+        return max(0, int(np.floor(abs(v) + 0.5) * np.sign(v)))
+
+    def _fill(self, desc):
+        desc.generator_kind = _abi.CS_GEN_MONOTONIC
+        desc.rate = self.rate
+        return []
+
+
+class SeededPoissonCrowd(CrowdGenerator):
+    """Seeded replacement for PoissonCrowd (source_sink.rs:63-82, whose
+    thread_rng cannot be seeded): Poisson(dt * rate) from a counter-based
+    generator keyed by (seed, step index)."""
+
+    def __init__(self, rate, seed):
+        self.rate = float(rate)
+        self.seed = int(seed)
+
+    def _fill(self, desc):
+        desc.generator_kind = _abi.CS_GEN_POISSON_SEEDED
+        desc.rate = self.rate
+        desc.seed = self.seed
+        return []
+
+
+@dataclass
+class SourceSink:
+    """struct SourceSink, source_sink.rs:36-60."""
+    source: tuple
+    radius_sink: float
+    crowd_generator: CrowdGenerator
+    high_level_planner: HighLevelPlanner
+    local_planner: LocalPlanner
+    waypoints: list
+    loop_forever: bool
+    agent_eyesight_range: float
+
+
+# ---- listeners -------------------------------------------------------------
+class EventListener:
+    """trait EventListener, lib.rs:22-33."""
+
+    def agent_spawned(self, position, agent):
+        pass
+
+    def agent_destroyed(self, agent):
+        pass
+
+    def waypoint_reached(self, position, agent):
+        """Declared by the reference, never called (lib.rs:32)."""
+
+
+# ---- the simulation --------------------------------------------------------
+class Simulation:
+    """Simulation<LocationHash2D>, lib.rs:69-383, on one MI355X."""
+
+    def __init__(self, spatial_index, device=0, flags=_abi.CS_CFG_DEFAULT, capacity_hint=0,
+                 stream=None, tile=None):
+        self._lib = self._load_library()
+        grid = spatial_index._desc()
+        cfg = _abi.DeviceCfg(int(device), int(flags), 0, 0, 0, 0, int(capacity_hint),
+                             C.c_void_p(stream) if stream else None)
+        if tile is not None:
+            cfg.tile_cx0, cfg.tile_cx1, cfg.tile_cy0, cfg.tile_cy1 = [int(t) for t in tile]
+        self.spatial_index = spatial_index
+        self._engine = self._lib.cs_create(C.byref(grid), C.byref(cfg))
+        if not self._engine:
+            raise CrowdSimError("cs_create failed (no usable HIP device?)")
+        self._planner_handles = {}
+        self._planners_alive = []
+        self._listeners = {}
+        self._next_listener = 0
+        self._source_sinks = {}
+        self._agents_cache = None
+        self.last_report = None
+
+    def _load_library(self):
+        return _native.load()
+
+    def close(self):
+        if getattr(self, "_engine", None):
+            self._lib.cs_destroy(self._engine)
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers --
+    @property
+    def backend(self):
+        return self._lib.cs_backend_name(self._engine).decode()
+
+    def _err(self):
+        return CrowdSimError(self._lib.cs_last_error(self._engine).decode())
+
+    def _handle(self, planner):
+        key = id(planner)
+        if key not in self._planner_handles:
+            self._planner_handles[key] = planner._register(self._lib, self._engine)
+            self._planners_alive.append(planner)
+        return self._planner_handles[key]
+
+    def _dispatch_events(self):
+        buf = (_abi.Event * 4096)()
+        while True:
+            n = self._lib.cs_drain_events(self._engine, buf, len(buf))
+            for i in range(n):
+                ev = buf[i]
+                for listener in self._listeners.values():
+                    if ev.kind == _abi.CS_EVENT_SPAWNED:
+                        listener.agent_spawned(np.array([ev.x, ev.y]), int(ev.id))
+                    elif ev.kind == _abi.CS_EVENT_DESTROYED:
+                        listener.agent_destroyed(int(ev.id))
+            if n < len(buf):
+                break
+
+    # -- reference API --
+    def add_agents(self, spawn_positions, high_level_planner, local_planner,
+                   agent_eyesight_range):
+        """lib.rs:119-156 -> list of agent ids (sequential from the last allocated id)."""
+        pts = np.ascontiguousarray(np.asarray(spawn_positions, dtype=np.float64).reshape(-1, 2))
+        n = pts.shape[0]
+        ids = np.zeros(n, dtype=np.uint64)
+        rc = self._lib.cs_add_agents(
+            self._engine, pts.ctypes.data_as(C.POINTER(C.c_double)), n,
+            self._handle(high_level_planner), self._handle(local_planner),
+            float(agent_eyesight_range), ids.ctypes.data_as(C.POINTER(C.c_uint64)))
+        self._agents_cache = None
+        self._dispatch_events()
+        if rc != 0:
+            raise self._err()
+        return [int(i) for i in ids]
+
+    def add_source_sink(self, source_sink):
+        """lib.rs:159-161 -> handle"""
+        wps = np.ascontiguousarray(np.asarray(source_sink.waypoints, dtype=np.float64).reshape(-1, 2))
+        desc = _abi.SourceSinkDesc()
+        desc.source_x, desc.source_y = float(source_sink.source[0]), float(source_sink.source[1])
+        desc.radius_sink = float(source_sink.radius_sink)
+        keep = source_sink.crowd_generator._fill(desc)
+        desc.hlp = self._handle(source_sink.high_level_planner)
+        desc.lp = self._handle(source_sink.local_planner)
+        desc.waypoints_xy = wps.ctypes.data_as(C.POINTER(C.c_double))
+        desc.n_waypoints = wps.shape[0]
+        desc.loop_forever = 1 if source_sink.loop_forever else 0
+        desc.agent_eyesight_range = float(source_sink.agent_eyesight_range)
+        handle = self._lib.cs_add_source_sink(self._engine, C.byref(desc))
+        self._source_sinks[handle] = (source_sink, keep)
+        return handle
+
+    def remove_source_sink(self, handle):
+        """lib.rs:164-168"""
+        self._lib.cs_remove_source_sink(self._engine, int(handle))
+        self._source_sinks.pop(handle, None)
+
+    def add_event_listener(self, event_listener):
+        """lib.rs:171-173 -> handle"""
+        handle = self._next_listener
+        self._next_listener += 1
+        self._listeners[handle] = event_listener
+        return handle
+
+    def remove_agents(self, agent):
+        """lib.rs:176-192 (an unknown id raises instead of panicking)."""
+        rc = self._lib.cs_remove_agent(self._engine, int(agent))
+        self._agents_cache = None
+        self._dispatch_events()
+        if rc != 0:
+            raise self._err()
+
+    def step(self, dur, report=True):
+        """lib.rs:195-383.  `dur`: seconds (float) or datetime.timedelta."""
+        dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
+        rep = _abi.StepReport()
+        need_report = report or bool(self._listeners)
+        rc = self._lib.cs_step(self._engine, dt, C.byref(rep) if need_report else None)
+        self._agents_cache = None
+        if need_report:
+            self.last_report = rep.as_dict()
+        if self._listeners or rc != 0:
+            self._dispatch_events()
+        if rc != 0:
+            raise self._err()
+
+    def synchronize(self):
+        if self._lib.cs_synchronize(self._engine) != 0:
+            raise self._err()
+
+    # -- observation --
+    def read_agents(self):
+        """Structured array (id, x, y, vx, vy, next_waypoint, eyesight_range), ascending id."""
+        n = self._lib.cs_agent_count(self._engine)
+        buf = (_abi.AgentView * max(n, 1))()
+        got = self._lib.cs_read_agents(self._engine, buf, n)
+        arr = np.frombuffer(buf, dtype=np.dtype([
+            ("id", "<u8"), ("x", "<f8"), ("y", "<f8"), ("vx", "<f8"), ("vy", "<f8"),
+            ("next_waypoint", "<u8"), ("eyesight_range", "<f8")]), count=got)
+        return arr.copy()
+
+    @property
+    def agents(self):
+        """`pub agents: HashMap<AgentId, Agent>` (lib.rs:71), read back lazily."""
+        if self._agents_cache is None:
+            arr = self.read_agents()
+            self._agents_cache = {
+                int(r["id"]): Agent(int(r["id"]), np.array([r["x"], r["y"]]),
+                                    np.array([r["vx"], r["vy"]]), int(r["next_waypoint"]),
+                                    float(r["eyesight_range"]))
+                for r in arr}
+        return self._agents_cache
+
+    def __len__(self):
+        return int(self._lib.cs_agent_count(self._engine))
+
+    def get_neighbours_in_radius(self, radius, position):
+        """SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258."""
+        cap = 256
+        while True:
+            out = np.zeros(cap, dtype=np.uint64)
+            n = self._lib.cs_query_radius(self._engine, float(radius), float(position[0]),
+                                          float(position[1]),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+            if n <= cap:
+                return [int(i) for i in out[:n]]
+            cap = int(n)
+
+    def get_nearest_neighbours(self, n, position):
+        """SpatialIndex::get_nearest_neighbours, location_hash_2d.rs:151-238."""
+        out = np.zeros(max(int(n), 1) + len(self), dtype=np.uint64)
+        got = self._lib.cs_query_knn(self._engine, int(n), float(position[0]), float(position[1]),
+                                     out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return [int(i) for i in out[:got]]
+
+    # -- measurement --
+    def profile_enable(self, on=True):
+        self._lib.cs_profile_enable(self._engine, 1 if on else 0)
+
+    def profile_reset(self):
+        self._lib.cs_profile_reset(self._engine)
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(_abi.KERNEL_NAMES):
+            ms, cnt = C.c_double(0), C.c_uint64(0)
+            self._lib.cs_profile_read(self._engine, k, C.byref(ms), C.byref(cnt))
+            out[name] = {"total_ms": ms.value, "launches": int(cnt.value)}
+        return out

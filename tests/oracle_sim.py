@@ -1,0 +1,44 @@
+"""Test-only binding of the CPU oracle (oracle/crowdstep_oracle.cpp) behind the same
+Python surface as the product, so a scenario can be replayed on both."""
+import ctypes
+import os
+import subprocess
+
+from rmf_crowdsim_amd import _abi
+from rmf_crowdsim_amd.simulation import Simulation
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_libs = {}
+
+
+def load_oracle(kind="f64"):
+    if kind in _libs:
+        return _libs[kind]
+    name = "libcrowdstep_oracle.so" if kind == "f64" else "libcrowdstep_oracle_f32.so"
+    path = os.path.join(ORACLE_DIR, "_build", name)
+    src = os.path.join(ORACLE_DIR, "crowdstep_oracle.cpp")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    lib = _abi.bind(ctypes.CDLL(path))
+    lib.oracle_time_to_collision.restype = ctypes.c_double
+    lib.oracle_time_to_collision.argtypes = [ctypes.c_double] * 5
+    lib.oracle_index_add_or_update.restype = ctypes.c_int
+    lib.oracle_index_add_or_update.argtypes = [ctypes.c_void_p, ctypes.c_uint64,
+                                               ctypes.c_double, ctypes.c_double]
+    lib.oracle_index_remove.restype = None
+    lib.oracle_index_remove.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    _libs[kind] = lib
+    return lib
+
+
+class OracleSimulation(Simulation):
+    """`Simulation` whose engine is the f64 CPU oracle.  Tests only."""
+    _kind = "f64"
+
+    def _load_library(self):
+        return load_oracle(self._kind)
+
+
+class OracleSimulationF32(OracleSimulation):
+    _kind = "f32"
