@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — agent-steps/sec of the MI355X crowd-step engine (BASELINE.json metric).
+
+A "step" is one Simulation::step (lib.rs:195-383 of the reference) over the whole synthetic
+crowd: cell re-sort (scan + scatter) + the Zanlungo neighbour kernel + integration.  State is
+resident in HBM before the timed region; nothing is read back inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--agents A] [--eyesight E] [--cell C]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
+one rank per GPU, weak scaling (every rank steps its own --agents crowd).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Algorithmic HBM bytes of the neighbour kernel per agent per launch (DESIGN.md "K4"):
+# read own record off 8 + vel 8 + id 4 + cell 4 + meta 4 = 28 and the cell table 4 B/cell
+# amortised (counted per agent below); write off 8 + vel 8 + id 4 + meta 4 + cell 4 + rank 4 = 32.
+K4_READ_BYTES = 28
+K4_WRITE_BYTES = 32
+
+
+def build_crowd(sim_cls, n, cell, eyesight, speed, device=0, stream=None, capacity=0):
+    from rmf_crowdsim_amd import LocationHash2D, Zanlungo, scenes
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell)
+    kwargs = {}
+    if sim_cls.__name__ == "Simulation":
+        kwargs = dict(device=device, stream=stream, capacity_hint=capacity)
+    sim = sim_cls(LocationHash2D(**grid), **kwargs)
+    scenes.add_counterflow(sim, pts, group, speed, Zanlungo(*scenes.METRIC_ZANLUNGO), eyesight)
+    return sim, grid, extent
+
+
+def cpu_baseline(agents, cell, eyesight, speed, budget_s=20.0):
+    """Times the CPU oracle (the reference-shaped single-thread port) on a bounded sample of the
+    same workload: same density / parameters, fewer agents, a few steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_sim import OracleSimulation
+    n = min(agents, 100_000)
+    sim, _, _ = build_crowd(OracleSimulation, n, cell, eyesight, speed)
+    sim.step(0.05)  # first step: all velocities 0 -> no forces; not representative
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        sim.step(0.05)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 20:
+            break
+    return {
+        "value": n * steps / el, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{n} agents x {steps} steps of the same scene (density, planner, eyesight, dt), "
+                  f"oracle/crowdstep_oracle.cpp f64 single thread, {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--agents", type=int, default=1_000_000, help="agents per GPU")
+    ap.add_argument("--eyesight", type=float, default=2.0)
+    ap.add_argument("--cell", type=float, default=2.0)
+    ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
+    ap.add_argument("--kernel", choices=["auto", "tiled", "gather"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rmf_crowdsim_amd import Simulation, scenes, _abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    speed = scenes.CREEP_SPEED if args.speed is None else args.speed
+    flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel]
+
+    stream = torch.cuda.current_stream().cuda_stream
+    from rmf_crowdsim_amd import LocationHash2D, Zanlungo
+    pts, grid, extent, group = scenes.uniform_crowd(args.agents, seed=7 + rank, cell_size=args.cell)
+    sim = Simulation(LocationHash2D(**grid), device=local_rank, flags=flags, stream=stream,
+                     capacity_hint=args.agents + 1024)
+    scenes.add_counterflow(sim, pts, group, speed, Zanlungo(*scenes.METRIC_ZANLUNGO), args.eyesight)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sim.step(0.05, report=False)
+    sim.synchronize()
+    sim.profile_reset()
+    sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)  # hipEvents around K4, on its own stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step(0.05, report=False)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    sim.profile_enable(0)
+    prof = sim.profile_read()
+    sim.synchronize()  # surfaces "Index out of bounds" if any step left the grid
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # the scene must still be the scene: everyone alive and finite
+    sim.step(0.05)
+    rep = sim.last_report
+    total_agents = args.agents * world
+    k4 = prof["neighbour_force"]
+    k4_ms = k4["total_ms"] / max(k4["launches"], 1)
+    ncells = int(round(grid["width"] / grid["cell_size"])) ** 2
+    alg_bytes = args.agents * (K4_READ_BYTES + K4_WRITE_BYTES) + 4 * ncells
+    achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "agent-steps/sec at 1M agents, dt=0.05 s; % HBM roofline on Zanlungo kernel",
+            "value": total_agents * args.steps / elapsed,
+            "unit": "agent-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.agents} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered "
+                            f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
+                            f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s",
+                "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
+                "speed": speed, "kernel": args.kernel,
+                "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas",
+                "n_tti_zero": rep["n_tti_zero"], "n_nonfinite": rep["n_nonfinite"],
+                "n_agents_alive": rep["n_agents"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
+                "kernel_ms": k4_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.agents, args.cell, args.eyesight, speed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

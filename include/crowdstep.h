@@ -225,9 +225,9 @@ enum {
   CS_K_HALO = 4,            /* halo pack/unpack (K7)                     */
   CS_K_COUNT = 5
 };
-/* Turn per-kernel hipEvent timing on/off (events are recorded on the engine's
- * stream around each launch). */
-void cs_profile_enable(cs_engine*, int on);
+/* Per-kernel hipEvent timing: bit k of kernel_mask times kernel CS_K_k (events are
+ * recorded on the engine's stream around each launch); 0 turns timing off. */
+void cs_profile_enable(cs_engine*, uint32_t kernel_mask);
 /* Sum of durations (ms) and launch count since the last reset. */
 int cs_profile_read(cs_engine*, uint32_t kernel, double* total_ms, uint64_t* launches);
 void cs_profile_reset(cs_engine*);

@@ -20,7 +20,7 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # IEEE behaviour the Zanlungo NaN/inf semantics rely on (DESIGN.md "Numerics")
     "-ffp-contract=off", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-value",
 ]
 
 _lib = None

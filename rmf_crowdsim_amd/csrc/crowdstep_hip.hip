@@ -1,0 +1,2054 @@
+// crowdstep_hip.hip — MI355X (gfx950) engine behind include/crowdstep.h.
+//
+// The per-step hot path of rmf_crowdsim's Simulation::step (reference
+// rmf_crowdsim/src/lib.rs:195-383) as HIP kernels over cell-sorted SoA agent
+// state.  See DESIGN.md for the data layout and the per-kernel rooflines.
+//
+//   k_count     cell histogram + arrival rank            (location_hash_2d.rs:126-149)
+//   k_scan_*    exclusive scan of the cell counts        (implicit in Vec<HashSet>, :15)
+//   k_scatter   reorder records into cell order          (:139-147)
+//   k_step_*    neighbour query + Zanlungo + integrate + re-bin + waypoint/sink test
+//               (location_hash_2d.rs:240-258, zanlungo.rs:49-217, lib.rs:259-359)
+//   k_spawn     source occupancy + append                (lib.rs:199-254)
+//
+// Device state is f32 and CELL-RELATIVE: an agent is (stored cell, offset from
+// that cell's origin), so relative positions between neighbours keep ~1e-7 m
+// resolution at any domain size.  f64 appears only at the ABI.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "crowdstep.h"
+
+#define CS_INVALID_CELL 0xFFFFFFFFu
+#define CS_MAX_GROUPS 4096u
+#define CS_SPAWN_OCCUPANCY_RADIUS 0.4  // hard-coded in the reference, lib.rs:212-214
+
+// ---------------------------------------------------------------------------
+// device-side tables
+// ---------------------------------------------------------------------------
+struct GridDev {
+  uint32_t nx;      // row stride AND number of x rows: (width / cell) as usize
+  uint32_t ny;      // (height / cell) as usize
+  uint32_t ncells;  // nx * ny
+  float cs;         // cell size, f32
+  float cs_lo;      // cell_size - (double)cs, second word for exact re-basing
+  float inv_cs;
+};
+
+// One group per add_agents call / per source-sink: the reference passes the
+// planners and the eyesight per call (lib.rs:119-125, source_sink.rs:46-59).
+struct GroupDev {
+  float eyesight;
+  uint32_t lp_kind;  // 0 = NoLocalPlan, 1 = Zanlungo
+  float A, D, inv_mass, R;
+  uint32_t hlp_kind;  // CS_HLP_*
+  float hvx, hvy;
+  int32_t sink;  // owning source-sink slot or -1
+};
+
+struct SinkDev {
+  double src_x, src_y;  // global, for events
+  uint32_t src_cell;    // stored cell of the source point (or CS_INVALID_CELL)
+  float src_ox, src_oy;
+  float radius_sink;
+  uint32_t wp_begin, wp_count;  // into the waypoint array (global f64 pairs)
+  uint32_t loop_forever;
+  uint32_t group;
+  float eyesight;
+};
+
+struct Counters {
+  // persistent
+  uint32_t n_alive;          // written by the scan: total of the histogram
+  uint32_t n_out_of_bounds;  // cumulative: any non-zero value poisons the engine
+  // per step (zeroed before each step)
+  uint32_t n_destroyed;
+  uint32_t n_waypoint_hits;
+  uint32_t n_tti_zero;
+  uint32_t n_nonfinite;
+  uint32_t n_clamped;
+  uint32_t n_spawned;
+  uint32_t n_wp_events;
+  uint32_t pad[7];
+};
+#define CS_COUNTERS_PER_STEP_OFFSET (2 * sizeof(uint32_t))
+
+struct AgentArrays {
+  float2* off;
+  float2* vel;
+  uint32_t* id;
+  uint32_t* cell;  // stored flat cell (reference's location_to_index), or CS_INVALID_CELL
+  uint32_t* meta;  // group (low 16) | next_waypoint (high 16)
+  uint32_t* rank;  // arrival rank inside `cell` for the next scatter
+};
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float f_inf() { return __builtin_huge_valf(); }
+__device__ __forceinline__ float f_nan() { return __builtin_nanf(""); }
+
+// Zanlungo::time_to_collision, zanlungo.rs:49-74 (collision distance is R, not 2R).
+// f32 has 1/8 of f64's exponent range: |rel_vel|^2 underflows near 1e-19 m/s where the
+// reference's f64 does not, and a flushed `a` with b != 0 would read as "colliding now"
+// (t0 = -inf, t1 = +inf -> 0).  Tiny relative velocities are therefore scaled by 2^48
+// first (t(s*rv) = t(rv)/s exactly), and what still underflows takes the a -> 0 limit of
+// the same quadratic, which is what f64 computes there.
+__device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float R2) {
+  float tscale = 1.0f;
+  if (fmaxf(fabsf(rvx), fabsf(rvy)) < 1e-12f) {
+    rvx *= 0x1p48f;
+    rvy *= 0x1p48f;
+    tscale = 0x1p48f;
+  }
+  float a = rvx * rvx + rvy * rvy;
+  float b = 2.0f * (rvx * rpx + rvy * rpy);
+  float c = (rpx * rpx + rpy * rpy) - R2;
+  if (a < 1e-30f) {
+    if (b == 0.0f) return f_inf();      // equal velocities: 0/0 = NaN fails every comparison
+    if (c < 0.0f) return 0.0f;          // already inside R: t0 < 0 < t1
+    return b < 0.0f ? (-c / b) * tscale : f_inf();
+  }
+  float disc = b * b - 4.0f * a * c;
+  if (disc < 0.0f) return f_inf();
+  float root = sqrtf(disc);
+  float den = 2.0f * a;
+  float t0 = (-b - root) / den;
+  float t1 = (-b + root) / den;
+  if ((t0 < 0.0f && t1 > 0.0f) || (t1 < 0.0f && t0 > 0.0f)) return 0.0f;
+  if (t0 < t1 && t0 > 0.0f) return t0 * tscale;
+  if (t1 > 0.0f) return t1 * tscale;
+  return f_inf();
+}
+
+// Force on agent i from a neighbour j with the LARGER id (weight = 2 branch of
+// compute_agent_force, zanlungo.rs:93-170, with right_of_way_vel :173-198 and
+// slerp :23-28 folded for the state the reference actually produces: a
+// neighbour's preferred_vel is always (0,0) (lib.rs:140,261,271: it is set on
+// the per-iteration clone only), so other_vel = v_j + 1*(0 - v_j) = 0 and the
+// "stationary" branch :119-125 is the live one; slerp(1, d, perp, s) =
+// d*(sin(0)/s) + perp*(sin(asin s)/s) = d*0 + perp*1 for s > 0 and NaN for s == 0,
+// and the following normalize() removes the factor sin(asin s)/s = 1 +- 1 ulp).
+//   rp = p_j - p_i, futx/futy = v_i * T, mag = min(1e15, 2*A*|v_i| / T)
+__device__ __forceinline__ void zanlungo_forward_force(float rpx, float rpy, float vix, float viy,
+                                                       float futx, float futy, float mag,
+                                                       float two_R, float D, float& fx,
+                                                       float& fy) {
+  float dx = futx - rpx, dy = futy - rpy;  // (p_i + v_i T) - (p_j + 0 T)
+  float dist = sqrtf(dx * dx + dy * dy);
+  float px = rpy, py = -rpx;  // perp of q = p_i - p_j = -rp: (-q.y, q.x)
+  if (px * vix + py * viy < 0.0f) {
+    px = -px;
+    py = -py;
+  }
+  float s = fabsf(px * dy - py * dx);
+  // s > 1 clamps to 1 and drops out; s == 0 or NaN poisons the direction (0/0)
+  if (!(s > 0.0f)) {
+    px = f_nan();
+    py = f_nan();
+  }
+  float en = sqrtf(px * px + py * py);
+  float nx = px / en, ny = py / en;
+  float surface = dist - two_R;
+  float scale = mag * expf(-surface / D);
+  fx += nx * scale;
+  fy += ny * scale;
+}
+
+struct StepParams {
+  GridDev g;
+  float dt;
+  uint32_t n;  // slots in the sorted arrays (upper bound of alive)
+  uint32_t has_sinks;
+  uint32_t n_src_cells;  // 0 when no sources are binned
+};
+
+// Re-bin after integration: the reference's location_to_index
+// (location_hash_2d.rs:54-66) on a cell-relative position.  Negative
+// coordinates saturate to row/column 0, y beyond the stride aliases into the
+// next row, flat >= len is "Index out of bounds".
+__device__ __forceinline__ uint32_t rebin(const GridDev& g, uint32_t gx, uint32_t gy, float& ox,
+                                          float& oy, Counters* ctr) {
+  float kxf = floorf(ox * g.inv_cs), kyf = floorf(oy * g.inv_cs);
+  if (kxf == 0.0f && kyf == 0.0f) return gx * g.nx + gy;  // fast path: same cell
+  bool nanx = !(ox == ox), nany = !(oy == oy);
+  // NaN as usize = 0 (saturating cast): binned into row/column 0, offset stays NaN
+  long long cx = nanx ? 0 : (long long)gx + (long long)fminf(fmaxf(kxf, -4e9f), 4e9f);
+  long long cy = nany ? 0 : (long long)gy + (long long)fminf(fmaxf(kyf, -4e9f), 4e9f);
+  bool clamped = false;
+  if (cx < 0) {
+    cx = 0;
+    clamped = !nanx;
+  }
+  if (cy < 0) {
+    cy = 0;
+    clamped = clamped || !nany;
+  }
+  if (clamped) atomicAdd(&ctr->n_clamped, 1u);
+  unsigned long long flat = (unsigned long long)cx * g.nx + (unsigned long long)cy;
+  if (flat >= g.ncells) {
+    atomicAdd(&ctr->n_out_of_bounds, 1u);
+    return CS_INVALID_CELL;
+  }
+  // geometric coordinates of the STORED cell (differ from (cx,cy) when aliased)
+  uint32_t sx = (uint32_t)cx, sy = (uint32_t)cy;
+  if (cy >= g.nx) {
+    sx = (uint32_t)(flat / g.nx);
+    sy = (uint32_t)(flat % g.nx);
+  }
+  float mx = (float)((long long)sx - (long long)gx), my = (float)((long long)sy - (long long)gy);
+  ox = (ox - mx * g.cs) - mx * g.cs_lo;
+  oy = (oy - my * g.cs) - my * g.cs_lo;
+  return (uint32_t)flat;
+}
+
+// Source occupancy for the next spawn phase: the reference asks the index for
+// agents within 0.4 of each source (lib.rs:212-217); here every agent marks the
+// sources it blocks.  Sources are binned once on the host (src_cell_start /
+// src_sorted, same cell order as the agents).
+__device__ __forceinline__ void mark_sources(const GridDev& g, const SinkDev* __restrict__ sinks,
+                                             const uint32_t* __restrict__ src_cell_start,
+                                             const uint32_t* __restrict__ src_sorted,
+                                             uint32_t* __restrict__ src_occupied, uint32_t cell,
+                                             float ox, float oy) {
+  const float r = (float)CS_SPAWN_OCCUPANCY_RADIUS;
+  if (!(fabsf(ox) < 1e6f * g.cs && fabsf(oy) < 1e6f * g.cs)) return;  // NaN / far outside
+  const uint32_t sx = cell / g.nx, sy = cell - sx * g.nx;
+  long long lx = (long long)sx + (long long)floorf((ox - r) * g.inv_cs - 1e-4f);
+  long long hx = (long long)sx + (long long)floorf((ox + r) * g.inv_cs + 1e-4f);
+  long long ly = (long long)sy + (long long)floorf((oy - r) * g.inv_cs - 1e-4f);
+  long long hy = (long long)sy + (long long)floorf((oy + r) * g.inv_cs + 1e-4f);
+  lx = max(lx, 0ll); ly = max(ly, 0ll);
+  hx = min(hx, (long long)g.nx - 1); hy = min(hy, (long long)g.nx - 1);
+  for (long long cx = lx; cx <= hx; ++cx) {
+    for (long long cy = ly; cy <= hy; ++cy) {
+      unsigned long long flat = (unsigned long long)cx * g.nx + (unsigned long long)cy;
+      if (flat >= g.ncells) continue;
+      uint32_t b = src_cell_start[flat], e = src_cell_start[flat + 1];
+      for (uint32_t k = b; k < e; ++k) {
+        uint32_t slot = src_sorted[k];
+        float qx = (float)(cx - (long long)sx) * g.cs + (sinks[slot].src_ox - ox);
+        float qy = (float)(cy - (long long)sy) * g.cs + (sinks[slot].src_oy - oy);
+        if (sqrtf(qx * qx + qy * qy) < r) src_occupied[slot] = 1u;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1: histogram + arrival rank (used when the histogram kept by k_step is stale)
+// ---------------------------------------------------------------------------
+__global__ void k_count(AgentArrays a, uint32_t first, uint32_t n, uint32_t* __restrict__ cell_count) {
+  uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = a.cell[i];
+  if (c == CS_INVALID_CELL) return;
+  a.rank[i] = atomicAdd(&cell_count[c], 1u);
+}
+
+__global__ void k_mark_sources(GridDev g, AgentArrays a, uint32_t n, const SinkDev* __restrict__ sinks,
+                               const uint32_t* __restrict__ src_cell_start,
+                               const uint32_t* __restrict__ src_sorted,
+                               uint32_t* __restrict__ src_occupied) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = a.cell[i];
+  if (c == CS_INVALID_CELL) return;
+  float2 o = a.off[i];
+  mark_sources(g, sinks, src_cell_start, src_sorted, src_occupied, c, o.x, o.y);
+}
+
+// ---------------------------------------------------------------------------
+// K2: exclusive scan of cell_count -> cell_start (and zero cell_count)
+//   pass A: per-block totals; pass B: block offset by summing earlier totals,
+//   then an in-block scan.  1024 cells per block.
+// ---------------------------------------------------------------------------
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 4
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_totals(const uint32_t* __restrict__ cell_count,
+                                                            uint32_t ncells,
+                                                            uint32_t* __restrict__ block_totals) {
+  __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+  if (base + SCAN_ITEMS <= ncells) {
+    uint4 v = *reinterpret_cast<const uint4*>(cell_count + base);
+    s = v.x + v.y + v.z + v.w;
+  } else {
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+      if (base + k < ncells) s += cell_count[base + k];
+  }
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += wsum[w];
+    block_totals[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict__ cell_count,
+                                                           uint32_t ncells,
+                                                           const uint32_t* __restrict__ block_totals,
+                                                           uint32_t nblocks,
+                                                           uint32_t* __restrict__ cell_start,
+                                                           Counters* __restrict__ ctr) {
+  __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+  __shared__ uint32_t s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // offset of this block = sum of the totals of the blocks before it
+  uint32_t part = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_BLOCK) part += block_totals[b];
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+  if (lane == 0) wsum[wave] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += wsum[w];
+    s_base = t;
+  }
+  __syncthreads();
+  const uint32_t block_base = s_base;
+  __syncthreads();
+
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  bool full = base + SCAN_ITEMS <= ncells;
+  if (full) {
+    uint4 q = *reinterpret_cast<const uint4*>(cell_count + base);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    *reinterpret_cast<uint4*>(cell_count + base) = make_uint4(0, 0, 0, 0);
+  } else {
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k) {
+      v[k] = (base + k < ncells) ? cell_count[base + k] : 0u;
+      if (base + k < ncells) cell_count[base + k] = 0u;
+    }
+  }
+  uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = wave_incl_scan(tsum, lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  uint32_t excl = block_base + woff + incl - tsum;
+  uint32_t o0 = excl, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
+  if (full) {
+    *reinterpret_cast<uint4*>(cell_start + base) = make_uint4(o0, o1, o2, o3);
+  } else {
+    uint32_t o[4] = {o0, o1, o2, o3};
+    for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+      if (base + k < ncells) cell_start[base + k] = o[k];
+  }
+  // the thread holding the last cell publishes the grand total
+  if (base <= ncells - 1 && ncells - 1 < base + SCAN_ITEMS) {
+    uint32_t total = o3 + v[3];
+    if (!full) {
+      total = excl;
+      for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < ncells) total += v[k];
+    }
+    cell_start[ncells] = total;
+    ctr->n_alive = total;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: scatter records into cell order
+// ---------------------------------------------------------------------------
+__global__ void k_scatter(AgentArrays src, AgentArrays dst, uint32_t n,
+                          const uint32_t* __restrict__ cell_start) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = src.cell[i];
+  if (c == CS_INVALID_CELL) return;
+  uint32_t d = cell_start[c] + src.rank[i];
+  dst.off[d] = src.off[i];
+  dst.vel[d] = src.vel[i];
+  dst.id[d] = src.id[i];
+  dst.cell[d] = c;
+  dst.meta[d] = src.meta[i];
+}
+
+// ---------------------------------------------------------------------------
+// Shared epilogue of the step kernels: integrate, re-bin, waypoint/sink test,
+// histogram for the next scatter, source-occupancy marks.
+// (lib.rs:295-346; commit lib.rs:350-359 is the write into the `out` arrays)
+// ---------------------------------------------------------------------------
+struct EpilogueCtx {
+  AgentArrays out;
+  uint32_t* cell_count;
+  Counters* ctr;
+  const GroupDev* groups;
+  const SinkDev* sinks;
+  const double* waypoints;  // global f64 pairs
+  double grid_off_x, grid_off_y, cell_size;
+  uint2* destroyed;  // append list of (id, meta)
+  uint32_t destroyed_cap;
+  uint2* wp_events;  // (id, new next_waypoint) for host set_target callbacks
+  uint32_t wp_events_cap;
+  // source occupancy for the next step's spawn phase
+  const uint32_t* src_cell_start;  // per cell, into src_sorted
+  const uint32_t* src_sorted;      // sink slots sorted by source cell
+  uint32_t* src_occupied;
+};
+
+__device__ __forceinline__ void step_epilogue(const StepParams& P, const EpilogueCtx& E, uint32_t i,
+                                              uint32_t gx, uint32_t gy, float2 off, uint32_t id,
+                                              uint32_t meta, const GroupDev& grp, float wx, float wy) {
+  // waypoint / sink test on the OLD position (lib.rs:304-336)
+  uint32_t next_wp = meta >> 16;
+  bool destroyed = false;
+  if (grp.sink >= 0) {
+    const SinkDev& s = E.sinks[grp.sink];
+    if (next_wp >= s.wp_count) {
+      destroyed = true;  // "rogue agent", lib.rs:310-313
+    } else {
+      double wxg = E.waypoints[2 * (s.wp_begin + next_wp)];
+      double wyg = E.waypoints[2 * (s.wp_begin + next_wp) + 1];
+      // waypoint relative to this agent's cell origin, rounded once to f32
+      float rx = (float)(wxg - (E.grid_off_x + (double)gx * E.cell_size));
+      float ry = (float)(wyg - (E.grid_off_y + (double)gy * E.cell_size));
+      float ddx = off.x - rx, ddy = off.y - ry;
+      if (sqrtf(ddx * ddx + ddy * ddy) < s.radius_sink) {
+        atomicAdd(&E.ctr->n_waypoint_hits, 1u);
+        if (next_wp == s.wp_count - 1) {
+          if (s.loop_forever)
+            next_wp = 0;
+          else
+            destroyed = true;
+        } else {
+          next_wp += 1;
+          if (grp.hlp_kind == CS_HLP_CALLBACK) {
+            uint32_t k = atomicAdd(&E.ctr->n_wp_events, 1u);
+            if (k < E.wp_events_cap) E.wp_events[k] = make_uint2(id, next_wp);
+          }
+        }
+      }
+    }
+  }
+
+  // integrate (lib.rs:295-297): new_pos = pos + vel * dt, cell-relative
+  float nox = off.x + wx * P.dt, noy = off.y + wy * P.dt;
+  if (!(fabsf(nox) < f_inf() && fabsf(noy) < f_inf() && fabsf(wx) < f_inf() && fabsf(wy) < f_inf()))
+    atomicAdd(&E.ctr->n_nonfinite, 1u);
+  uint32_t ncell = rebin(P.g, gx, gy, nox, noy, E.ctr);
+
+  if (destroyed) {
+    uint32_t k = atomicAdd(&E.ctr->n_destroyed, 1u);
+    if (k < E.destroyed_cap) E.destroyed[k] = make_uint2(id, meta);
+    E.out.cell[i] = CS_INVALID_CELL;
+    return;
+  }
+  E.out.off[i] = make_float2(nox, noy);
+  E.out.vel[i] = make_float2(wx, wy);
+  E.out.id[i] = id;
+  E.out.meta[i] = (meta & 0xFFFFu) | (next_wp << 16);
+  E.out.cell[i] = ncell;
+  if (ncell == CS_INVALID_CELL) return;
+  E.out.rank[i] = atomicAdd(&E.cell_count[ncell], 1u);
+
+  if (P.has_sinks) mark_sources(P.g, E.sinks, E.src_cell_start, E.src_sorted, E.src_occupied, ncell, nox, noy);
+}
+
+// ---------------------------------------------------------------------------
+// K4: the neighbour pass.  Phase B of Simulation::step for one agent
+// (lib.rs:259-347): radius query (location_hash_2d.rs:240-258), Zanlungo
+// (zanlungo.rs:201-217).  One code path, two neighbour sources:
+//   TiledSrc   cell lists staged in LDS by the workgroup (the fast path)
+//   GatherSrc  cell lists read from global memory (exact for any grid and any
+//              agent state: clamped, aliased, overfull tiles)
+// Both visit cells x-major / y-minor and the members of a cell in ascending id
+// (the canonical order of SURVEY.md §8a'), with identical arithmetic, so their
+// results are bitwise equal.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 hlp_velocity(const GroupDev& grp, uint32_t id, const float2* pref,
+                                               uint32_t i) {
+  switch (grp.hlp_kind) {
+    case CS_HLP_CONSTANT:
+      return make_float2(grp.hvx, grp.hvy);
+    case CS_HLP_ID_PARITY:  // rmf_crowdsim_viz/src/main.rs:26-29: even ids get -v
+      return (id & 1u) ? make_float2(grp.hvx, grp.hvy) : make_float2(-grp.hvx, -grp.hvy);
+    case CS_HLP_CALLBACK:
+      return pref[i];
+    default:
+      return make_float2(0.0f, 0.0f);  // None: vel stays (0,0), lib.rs:263
+  }
+}
+
+struct Own {
+  float2 off, v, u;
+  uint32_t id, gx, gy, slot;
+};
+
+// Members of one cell straight from the sorted global arrays.
+struct GatherSrc {
+  const AgentArrays& in;
+  const uint32_t* __restrict__ cell_start;
+  const GridDev& g;
+  uint32_t self;
+  __device__ __forceinline__ bool cell(long long x, long long y, uint32_t& b, uint32_t& e) const {
+    if (x < 0 || y < 0) return false;  // signed_idx_to_data_idx, location_hash_2d.rs:74-85
+    unsigned long long flat = (unsigned long long)x * g.nx + (unsigned long long)y;
+    if (flat >= g.ncells) return false;
+    b = cell_start[flat];
+    e = cell_start[flat + 1];
+    return true;
+  }
+  __device__ __forceinline__ bool is_self(uint32_t j) const { return j == self; }
+  // offset of member j relative to the geometric cell (x, y) it was reached through;
+  // a member stored through the aliasing of location_to_index sits in another cell
+  __device__ __forceinline__ float2 off(uint32_t j, long long x, long long y) const {
+    float2 o = in.off[j];
+    if (y >= (long long)g.nx) {  // reached through an aliased flat index
+      uint32_t c = in.cell[j];
+      uint32_t ax = c / g.nx, ay = c - ax * g.nx;
+      o.x += (float)((long long)ax - x) * g.cs;
+      o.y += (float)((long long)ay - y) * g.cs;
+    }
+    return o;
+  }
+  __device__ __forceinline__ float2 vel(uint32_t j) const { return in.vel[j]; }
+  __device__ __forceinline__ uint32_t id(uint32_t j) const { return in.id[j]; }
+  // k-th member of [b, e) in ascending id: storage order inside a cell is arrival order
+  __device__ __forceinline__ uint32_t ordered(uint32_t b, uint32_t e, uint32_t k, uint32_t& last,
+                                              bool& have_last) const {
+    uint32_t best = 0xFFFFFFFFu, bj = b;
+    bool found = false;
+    for (uint32_t j = b; j < e; ++j) {
+      uint32_t idj = in.id[j];
+      if ((!have_last || idj > last) && (!found || idj < best)) {
+        best = idj;
+        bj = j;
+        found = true;
+      }
+    }
+    last = best;
+    have_last = true;
+    return bj;
+  }
+};
+
+// Members of one cell from the workgroup's LDS tile (already in ascending id).
+struct TiledSrc {
+  const float2* __restrict__ s_off;
+  const float2* __restrict__ s_vel;
+  const uint32_t* __restrict__ s_id;
+  const unsigned short* __restrict__ s_tab;  // [row][W + 1] first LDS slot of each staged cell
+  int r0, r1;  // staged rows
+  int sy0, sy1;  // staged cells of every row
+  int W1;        // W + 1
+  uint32_t self_id;
+  __device__ __forceinline__ bool cell(long long x, long long y, uint32_t& b, uint32_t& e) const {
+    if (x < r0 || x > r1 || y < sy0 || y > sy1) return false;
+    const unsigned short* t = s_tab + (int)(x - r0) * W1 + (int)(y - sy0);
+    b = t[0];
+    e = t[1];
+    return true;
+  }
+  __device__ __forceinline__ bool is_self(uint32_t j) const { return s_id[j] == self_id; }
+  __device__ __forceinline__ float2 off(uint32_t j, long long, long long) const { return s_off[j]; }
+  __device__ __forceinline__ float2 vel(uint32_t j) const { return s_vel[j]; }
+  __device__ __forceinline__ uint32_t id(uint32_t j) const { return s_id[j]; }
+  __device__ __forceinline__ uint32_t ordered(uint32_t b, uint32_t, uint32_t k, uint32_t&, bool&) const {
+    return b + k;
+  }
+};
+
+// Returns the new velocity w = u + F/m of agent `o` (zanlungo.rs:201-217).
+template <class Src>
+__device__ __forceinline__ void zanlungo_velocity(const Own& o, const GroupDev& grp, const GridDev& g,
+                                                  long long lx, long long hx, long long ly,
+                                                  long long hy, const Src& src, float& wx, float& wy,
+                                                  bool& tti_zero) {
+  const float r2 = grp.eyesight * grp.eyesight;
+  const float R2 = grp.R * grp.R;
+  // ---- compute_tti (zanlungo.rs:76-91): min over every neighbour in sight ----
+  float T = f_inf();
+  uint32_t n_back = 0;
+  for (long long x = lx; x <= hx; ++x) {
+    const float shx = (float)(x - (long long)o.gx) * g.cs;
+    for (long long y = ly; y <= hy; ++y) {
+      uint32_t b, e;
+      if (!src.cell(x, y, b, e)) continue;
+      const float shy = (float)(y - (long long)o.gy) * g.cs;
+      for (uint32_t j = b; j < e; ++j) {
+        if (src.is_self(j)) continue;  // lib.rs:284
+        const float2 oj = src.off(j, x, y);
+        const float rpx = shx + (oj.x - o.off.x), rpy = shy + (oj.y - o.off.y);  // p_j - p_i
+        if (!(rpx * rpx + rpy * rpy < r2)) continue;  // strict `<`, location_hash_2d.rs:251
+        const float2 vj = src.vel(j);
+        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, R2);
+        if (t < T) T = t;
+        n_back += (src.id(j) < o.id) ? 1u : 0u;
+      }
+    }
+  }
+  tti_zero = (T == 0.0f);
+  float fx = 0.0f, fy = 0.0f;
+  if (T != f_inf()) {  // zanlungo.rs:211
+    // compute_agent_force for the neighbours that have right of way (larger id)
+    const float futx = o.v.x * T, futy = o.v.y * T;
+    // weight * agent_scale * |my_vel - other_vel| / t_i with weight 2, other_vel 0
+    float mag = 2.0f * grp.A * sqrtf(o.v.x * o.v.x + o.v.y * o.v.y) / T;
+    if (mag >= 1e15f) mag = 1e15f;  // zanlungo.rs:165-167
+    const float two_R = grp.R * 2.0f;
+    for (long long x = lx; x <= hx; ++x) {
+      const float shx = (float)(x - (long long)o.gx) * g.cs;
+      for (long long y = ly; y <= hy; ++y) {
+        uint32_t b, e;
+        if (!src.cell(x, y, b, e)) continue;
+        const float shy = (float)(y - (long long)o.gy) * g.cs;
+        uint32_t last = 0;
+        bool have_last = false;
+        for (uint32_t k = 0; k < e - b; ++k) {
+          const uint32_t j = src.ordered(b, e, k, last, have_last);
+          if (!(src.id(j) > o.id)) continue;  // self and smaller ids: weight 0
+          const float2 oj = src.off(j, x, y);
+          const float rpx = shx + (oj.x - o.off.x), rpy = shy + (oj.y - o.off.y);
+          if (!(rpx * rpx + rpy * rpy < r2)) continue;
+          zanlungo_forward_force(rpx, rpy, o.v.x, o.v.y, futx, futy, mag, two_R, grp.D, fx, fy);
+        }
+      }
+    }
+    // Neighbours with a smaller id have weight 0: their term is (d/|d|) * 0 = 0, except
+    // with t_i == 0, where 0 * A * |dv| / 0 = NaN (zanlungo.rs:163; SURVEY.md KAT-Z3).
+    if (T == 0.0f && n_back > 0) {
+      fx = f_nan();
+      fy = f_nan();
+    }
+  }
+  wx = o.u.x + fx * grp.inv_mass;  // recommended + force * (1/m), zanlungo.rs:216
+  wy = o.u.y + fy * grp.inv_mass;
+}
+
+// get_bounds (location_hash_2d.rs:103-122) from a cell-relative position: cell range
+// [gx + lo, gx + hi] for radius r.  Saturating like Rust's `as i64`.
+__device__ __forceinline__ void cell_bounds(float o, float r, float inv_cs, long long g, long long& lo,
+                                            long long& hi) {
+  float fl = floorf((o - r) * inv_cs), fh = floorf((o + r) * inv_cs);
+  lo = g + (long long)fminf(fmaxf(fl, -4e9f), 4e9f);
+  hi = g + (long long)fminf(fmaxf(fh, -4e9f), 4e9f);
+}
+
+__device__ __forceinline__ void gather_agent(const StepParams& P, const AgentArrays& in,
+                                             const uint32_t* __restrict__ cell_start, const Own& o,
+                                             const GroupDev& grp, float& wx, float& wy, bool& tz) {
+  long long lx, hx, ly, hy;
+  cell_bounds(o.off.x, grp.eyesight, P.g.inv_cs, o.gx, lx, hx);
+  cell_bounds(o.off.y, grp.eyesight, P.g.inv_cs, o.gy, ly, hy);
+  // rows and cells that cannot exist: negative ones are rejected by the reference,
+  // flat indices beyond the grid too; y may run past the stride (aliasing) up to the
+  // last flat index
+  lx = max(lx, 0ll);
+  ly = max(ly, 0ll);
+  hx = min(hx, (long long)(P.g.ncells / P.g.nx));
+  hy = min(hy, (long long)P.g.ncells);
+  GatherSrc src{in, cell_start, P.g, o.slot};
+  zanlungo_velocity(o, grp, P.g, lx, hx, ly, hy, src, wx, wy, tz);
+}
+
+__global__ void __launch_bounds__(256) k_step_gather(StepParams P, AgentArrays in, EpilogueCtx E,
+                                                     const uint32_t* __restrict__ cell_start,
+                                                     const float2* __restrict__ pref) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (i >= E.ctr->n_alive) {
+    E.out.cell[i] = CS_INVALID_CELL;  // slot beyond the live population
+    return;
+  }
+  const uint32_t cell = in.cell[i];
+  Own o;
+  o.gx = cell / P.g.nx;
+  o.gy = cell - o.gx * P.g.nx;
+  o.off = in.off[i];
+  o.v = in.vel[i];
+  o.id = in.id[i];
+  o.slot = i;
+  const uint32_t meta = in.meta[i];
+  const GroupDev grp = E.groups[meta & 0xFFFFu];
+  o.u = hlp_velocity(grp, o.id, pref, i);
+  float wx = o.u.x, wy = o.u.y;  // NoLocalPlan: identity, no_local_plan.rs:9-17
+  if (grp.lp_kind == 1u && o.off.x == o.off.x && o.off.y == o.off.y) {
+    bool tz;
+    gather_agent(P, in, cell_start, o, grp, wx, wy, tz);
+    if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
+  }
+  step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
+}
+
+// ---------------------------------------------------------------------------
+// Work decomposition for the tiled kernel: every workgroup gets up to 256
+// consecutive agents of ONE grid row, so the cells it must see are (2h+1)
+// contiguous ranges of the sorted arrays.  Built on the device after the scan.
+// ---------------------------------------------------------------------------
+struct BlockDesc {
+  uint32_t row, first, count;
+};
+
+__global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t* __restrict__ cell_start,
+                                                       BlockDesc* __restrict__ desc, uint32_t desc_cap,
+                                                       uint32_t* __restrict__ n_blocks) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n_rows = g.ncells / g.nx;
+  for (uint32_t base = 0; base < n_rows; base += blockDim.x) {
+    uint32_t R = base + threadIdx.x;
+    uint32_t first = 0, cnt = 0;
+    if (R < n_rows) {
+      first = cell_start[(unsigned long long)R * g.nx];
+      cnt = cell_start[(unsigned long long)(R + 1) * g.nx] - first;
+    }
+    uint32_t nb = (cnt + 255u) / 256u;
+    uint32_t incl = wave_incl_scan(nb, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint32_t excl = s_carry + woff + incl - nb;
+    for (uint32_t k = 0; k < nb; ++k) {
+      if (excl + k < desc_cap) {
+        BlockDesc d;
+        d.row = R;
+        d.first = first + k * 256u;
+        d.count = min(256u, cnt - k * 256u);
+        desc[excl + k] = d;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_carry = excl + nb;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_blocks = min(s_carry, desc_cap);
+}
+
+#define TILE_MAX_ROWS 17  // 2 * 8 + 1: eyesight up to 8 cells
+
+struct TileCfg {
+  int h;                 // ceil(max eyesight / cell)
+  uint32_t agents_cap;   // LDS slots for staged agents
+  uint32_t table_cap;    // u16 entries of the cell table
+};
+
+// K4 (tiled form): one workgroup = one BlockDesc.
+__global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in, EpilogueCtx E,
+                                                    const uint32_t* __restrict__ cell_start,
+                                                    const float2* __restrict__ pref,
+                                                    const BlockDesc* __restrict__ desc,
+                                                    const uint32_t* __restrict__ n_blocks, TileCfg cfg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_g0[TILE_MAX_ROWS], s_base[TILE_MAX_ROWS + 1];
+  {  // slots beyond the live population must not look alive to the next scatter
+    const uint32_t t = E.ctr->n_alive + blockIdx.x * 256u + threadIdx.x;
+    if (t < P.n) E.out.cell[t] = CS_INVALID_CELL;
+  }
+  if (blockIdx.x >= *n_blocks) return;
+  const BlockDesc d = desc[blockIdx.x];
+  const GridDev g = P.g;
+  const int tid = threadIdx.x;
+  float2* s_off = reinterpret_cast<float2*>(smem);
+  float2* s_vel = s_off + cfg.agents_cap;
+  uint32_t* s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
+  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_id + cfg.agents_cap);
+
+  // ---- geometry of the strip and its halo ----
+  const int n_rows = (int)(g.ncells / g.nx);
+  const int R = (int)d.row;
+  const uint32_t c_lo = in.cell[d.first], c_hi = in.cell[d.first + d.count - 1];
+  const int ylo = (int)(c_lo - (uint32_t)R * g.nx), yhi = (int)(c_hi - (uint32_t)R * g.nx);
+  const int sy0 = max(ylo - cfg.h, 0), sy1 = min(yhi + cfg.h, (int)g.nx - 1);
+  const int W1 = sy1 - sy0 + 2;
+  const int r0 = max(R - cfg.h, 0), r1 = min(R + cfg.h, n_rows - 1);
+  const int nr = r1 - r0 + 1;
+  if (tid < nr) {
+    unsigned long long rowbase = (unsigned long long)(r0 + tid) * g.nx;
+    uint32_t g0 = cell_start[rowbase + sy0], g1 = cell_start[rowbase + sy1 + 1];
+    s_g0[tid] = g0;
+    s_base[tid + 1] = g1 - g0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    s_base[0] = 0;
+    for (int k = 0; k < nr; ++k) {
+      uint32_t c = s_base[k + 1];
+      s_base[k + 1] = acc + c;
+      acc += c;
+    }
+  }
+  __syncthreads();
+  const uint32_t S = s_base[nr];
+  const bool tiled_ok = S <= cfg.agents_cap && S < 65535u && (uint32_t)(nr * W1) <= cfg.table_cap;
+
+  if (tiled_ok) {
+    // cell table: first LDS slot of every staged cell (+ one end marker per row)
+    for (int t = tid; t < nr * W1; t += 256) {
+      int k = t / W1, y = t - k * W1;
+      unsigned long long rowbase = (unsigned long long)(r0 + k) * g.nx;
+      s_tab[t] = (unsigned short)(s_base[k] + (cell_start[rowbase + sy0 + y] - s_g0[k]));
+    }
+    // agents, each placed at its cell's first slot + its rank by id inside the cell
+    for (uint32_t s = tid; s < S; s += 256) {
+      int k = 0;
+      while (s >= s_base[k + 1]) ++k;
+      const uint32_t j = s_g0[k] + (s - s_base[k]);
+      const uint32_t cj = in.cell[j];
+      const uint32_t idj = in.id[j];
+      const uint32_t cb = cell_start[cj], ce = cell_start[cj + 1];
+      uint32_t rank = 0;
+      for (uint32_t q = cb; q < ce; ++q) rank += (in.id[q] < idj) ? 1u : 0u;
+      const uint32_t slot = s_base[k] + (cb - s_g0[k]) + rank;
+      s_off[slot] = in.off[j];
+      s_vel[slot] = in.vel[j];
+      s_id[slot] = idj;
+    }
+  }
+  __syncthreads();
+
+  if (tid >= (int)d.count) return;
+  const uint32_t i = d.first + tid;
+  const uint32_t cell = in.cell[i];
+  Own o;
+  o.gx = (uint32_t)R;
+  o.gy = cell - (uint32_t)R * g.nx;
+  o.off = in.off[i];
+  o.v = in.vel[i];
+  o.id = in.id[i];
+  o.slot = i;
+  const uint32_t meta = in.meta[i];
+  const GroupDev grp = E.groups[meta & 0xFFFFu];
+  o.u = hlp_velocity(grp, o.id, pref, i);
+  float wx = o.u.x, wy = o.u.y;
+  if (grp.lp_kind == 1u && o.off.x == o.off.x && o.off.y == o.off.y) {
+    bool tz;
+    // an agent whose offset left its cell (clamped below the grid, aliased above it)
+    // needs cells the strip did not stage
+    const float slack = 0.01f * g.cs;
+    const bool regular = o.off.x >= -slack && o.off.x <= g.cs + slack && o.off.y >= -slack &&
+                         o.off.y <= g.cs + slack;
+    bool use_tile = tiled_ok && regular;
+    long long lx = 0, hx = 0, ly = 0, hy = 0;
+    if (use_tile) {
+      cell_bounds(o.off.x, grp.eyesight, g.inv_cs, o.gx, lx, hx);
+      cell_bounds(o.off.y, grp.eyesight, g.inv_cs, o.gy, ly, hy);
+      use_tile = hy < (long long)g.nx;  // beyond the stride the reference aliases into the next row
+      // f32 rounding at a cell edge can ask for one cell beyond ceil(r / cell); that cell
+      // lies entirely out of reach
+      lx = max(lx, (long long)R - cfg.h);
+      hx = min(hx, (long long)R + cfg.h);
+      ly = max(ly, (long long)o.gy - cfg.h);
+      hy = min(hy, (long long)o.gy + cfg.h);
+    }
+    if (use_tile) {
+      TiledSrc src{s_off, s_vel, s_id, s_tab, r0, r1, sy0, sy1, W1, o.id};
+      zanlungo_velocity(o, grp, g, lx, hx, ly, hy, src, wx, wy, tz);
+    } else {
+      gather_agent(P, in, cell_start, o, grp, wx, wy, tz);
+    }
+    if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
+  }
+  step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
+}
+
+// ---------------------------------------------------------------------------
+// K6: spawn.  One block; sinks in ascending handle order.  A sink spawns ONE
+// agent at its source iff its generator asked for > 0 and nobody stood within
+// 0.4 of the source at the end of the previous step (lib.rs:199-254).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_spawn(AgentArrays a, uint32_t n_slots, uint32_t cap,
+                                                const SinkDev* __restrict__ sinks,
+                                                const uint32_t* __restrict__ want,  // per sink slot
+                                                uint32_t n_sinks, uint32_t n_want,
+                                                const uint32_t* __restrict__ src_occupied,
+                                                uint32_t* __restrict__ cell_count, uint32_t first_id,
+                                                uint32_t* __restrict__ spawned_slots,
+                                                Counters* __restrict__ ctr) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < n_sinks; base += blockDim.x) {
+    uint32_t s = base + threadIdx.x;
+    uint32_t flag = 0;
+    if (s < n_sinks)
+      flag = (want[s] > 0 && src_occupied[s] == 0 && sinks[s].src_cell != CS_INVALID_CELL) ? 1u : 0u;
+    uint32_t incl = wave_incl_scan(flag, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint32_t excl = s_carry + woff + incl - flag;
+    if (flag) {
+      uint32_t slot = n_slots + excl;
+      if (slot < cap) {
+        const SinkDev& sk = sinks[s];
+        a.off[slot] = make_float2(sk.src_ox, sk.src_oy);
+        a.vel[slot] = make_float2(0.0f, 0.0f);
+        a.id[slot] = first_id + excl;
+        a.cell[slot] = sk.src_cell;
+        a.meta[slot] = sk.group;  // next_waypoint = 0
+        a.rank[slot] = atomicAdd(&cell_count[sk.src_cell], 1u);
+        spawned_slots[excl] = s;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_carry = excl + flag;
+    __syncthreads();
+  }
+  // the host reserved n_want slots; the ones no sink used must not look alive
+  for (uint32_t k = s_carry + threadIdx.x; k < n_want; k += blockDim.x)
+    if (n_slots + k < cap) a.cell[n_slots + k] = CS_INVALID_CELL;
+  if (threadIdx.x == 0) ctr->n_spawned = s_carry;
+}
+
+// ---------------------------------------------------------------------------
+// radius query against the sorted state (SpatialIndex::get_neighbours_in_radius,
+// location_hash_2d.rs:240-258).  One block, cells in x-major / y-minor order;
+// used by cs_query_radius (host API), not by the step.
+// ---------------------------------------------------------------------------
+__global__ void k_query_radius(GridDev g, AgentArrays a, const uint32_t* __restrict__ cell_start,
+                               long long lx, long long hx, long long ly, long long hy,
+                               uint32_t qcx, uint32_t qcy, float qox, float qoy, float r,
+                               uint32_t* __restrict__ out_ids, uint32_t out_cap,
+                               uint32_t* __restrict__ out_count) {
+  // serial over cells (order matters), parallel inside a cell is not needed: tiny
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t n = 0;
+  for (long long x = lx; x <= hx; ++x) {
+    for (long long y = ly; y <= hy; ++y) {
+      if (x < 0 || y < 0) continue;
+      unsigned long long flat = (unsigned long long)x * g.nx + (unsigned long long)y;
+      if (flat >= g.ncells) continue;
+      uint32_t b = cell_start[flat], e = cell_start[flat + 1];
+      // ascending id inside the cell: selection order over the (small) cell
+      uint32_t last = 0;
+      bool first = true;
+      for (uint32_t k = b; k < e; ++k) {
+        uint32_t best = 0xFFFFFFFFu, bj = 0;
+        bool found = false;
+        for (uint32_t j = b; j < e; ++j) {
+          uint32_t idj = a.id[j];
+          if ((first || idj > last) && (!found || idj < best)) {
+            best = idj;
+            bj = j;
+            found = true;
+          }
+        }
+        if (!found) break;
+        last = best;
+        first = false;
+        uint32_t cj = a.cell[bj];
+        uint32_t ax = cj / g.nx, ay = cj - ax * g.nx;
+        float2 oj = a.off[bj];
+        float rx = (float)((long long)ax - (long long)qcx) * g.cs + (oj.x - qox);
+        float ry = (float)((long long)ay - (long long)qcy) * g.cs + (oj.y - qoy);
+        if (sqrtf(rx * rx + ry * ry) < r) {
+          if (n < out_cap) out_ids[n] = best;
+          ++n;
+        }
+      }
+    }
+  }
+  *out_count = n;
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+namespace {
+
+inline uint64_t sat_usize(double v) {
+  if (!(v > 0.0)) return 0;
+  if (v >= 18446744073709551615.0) return UINT64_MAX;
+  return (uint64_t)v;
+}
+
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// Seeded stand-in for PoissonCrowd (source_sink.rs:75-82, whose thread_rng is
+// unseedable): Knuth's product method on uniforms from splitmix64(seed, step,
+// draw).  Integer mixing + IEEE f64 products: the same sequence on any host.
+inline uint64_t poisson_seeded(uint64_t seed, uint64_t step, double mean) {
+  if (!(mean > 0.0)) return 0;
+  double limit = std::exp(-mean), prod = 1.0;
+  uint64_t k = 0;
+  for (uint64_t draw = 0; draw < 1000000; ++draw) {
+    uint64_t r = splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + draw));
+    double u = (double)((r >> 11) + 1) * (1.0 / 9007199254740993.0);
+    prod *= u;
+    if (prod <= limit) break;
+    ++k;
+  }
+  return k;
+}
+
+struct HostSink {
+  cs_source_sink_desc d;
+  std::vector<double> waypoints;
+  uint64_t calls = 0;
+  bool alive = true;
+  uint32_t group = 0;
+};
+
+struct HostGroup {
+  uint32_t hlp, lp;
+  double eyesight;
+  int32_t sink;
+};
+
+}  // namespace
+
+#define HIP_OK(call)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call;              \
+      return 90;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+struct cs_engine {
+  // grid (LocationHash2D::new, location_hash_2d.rs:33-51)
+  cs_grid_desc grid;
+  uint64_t nx = 0, ny = 0, ncells = 0;
+  GridDev gdev;
+  int device = 0;
+  uint32_t flags = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string error;
+  std::string backend;
+  bool poisoned = false;
+
+  // agent buffers: buf[cur] holds the state, buf[cur^1] is the scatter / step target
+  AgentArrays buf[2] = {};
+  int cur = 0;
+  uint64_t cap = 0;
+  uint32_t n_slots = 0;     // slots in use in buf[cur]
+  bool sorted = true;       // buf[cur] is in cell order, cell_start/n_alive match it
+  bool hist_valid = false;  // cell_count + rank describe buf[cur]
+  bool occ_valid = false;   // src_occupied describes the current positions
+  float2* pref = nullptr;   // callback-HLP velocities in sorted order
+  uint32_t* cell_count = nullptr;
+  uint32_t* cell_start = nullptr;
+  uint32_t* block_totals = nullptr;
+  uint32_t n_scan_blocks = 0;
+  Counters* ctr = nullptr;       // device
+  Counters* ctr_host = nullptr;  // pinned
+  uint2* destroyed = nullptr;
+  uint32_t destroyed_cap = 0;
+  uint2* wp_events = nullptr;
+  uint32_t wp_events_cap = 0;
+  BlockDesc* blk_desc = nullptr;  // work decomposition of the tiled neighbour kernel
+  uint32_t blk_desc_cap = 0;
+  uint32_t* n_blocks_dev = nullptr;
+  double max_eyesight = 0.0;
+
+  // planners as data
+  std::vector<cs_zanlungo_params> lp_params;
+  std::vector<uint32_t> lp_kinds;
+  std::vector<cs_hlp_desc> hlps;
+  std::vector<HostGroup> groups;
+  GroupDev* groups_dev = nullptr;
+  bool groups_dirty = true;
+  bool any_callback_hlp = false;
+
+  // source-sinks: slot == handle (registry.rs:16-21 hands out ascending integers)
+  std::vector<HostSink> sinks;
+  SinkDev* sinks_dev = nullptr;
+  double* waypoints_dev = nullptr;
+  uint32_t* src_cell_start = nullptr;
+  uint32_t* src_sorted = nullptr;
+  uint32_t* src_occupied = nullptr;
+  uint32_t* want_dev = nullptr;
+  uint32_t* spawned_slots_dev = nullptr;
+  bool sinks_dirty = true;
+  uint32_t n_live_sinks = 0;
+
+  uint64_t next_id = 0;  // last_alloc_agent_id, lib.rs:83
+  uint64_t n_alive_host = 0;
+  std::vector<cs_event> events;
+
+  // per-kernel hipEvent timing
+  uint32_t profiling = 0;  // bitmask of CS_K_* kernels to time
+  bool prof_open = false;
+  struct Timed {
+    hipEvent_t a, b;
+    uint32_t k;
+  };
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> event_pool;
+  double prof_ms[CS_K_COUNT] = {};
+  uint64_t prof_n[CS_K_COUNT] = {};
+
+  // ---- memory ----
+  int alloc_arrays(AgentArrays& a, uint64_t n) {
+    HIP_OK(hipMalloc(&a.off, n * sizeof(float2)));
+    HIP_OK(hipMalloc(&a.vel, n * sizeof(float2)));
+    HIP_OK(hipMalloc(&a.id, n * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&a.cell, n * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&a.meta, n * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&a.rank, n * sizeof(uint32_t)));
+    return 0;
+  }
+  void free_arrays(AgentArrays& a) {
+    hipFree(a.off); hipFree(a.vel); hipFree(a.id); hipFree(a.cell); hipFree(a.meta); hipFree(a.rank);
+    a = AgentArrays{};
+  }
+  int reserve(uint64_t need) {
+    if (need <= cap) return 0;
+    uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(1024, cap * 2));
+    if (ncap >= 0xFFFFFFF0ull) {
+      error = "agent capacity exceeds 32-bit slots";
+      return 4;
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    for (int b = 0; b < 2; ++b) {
+      AgentArrays na{};
+      if (int rc = alloc_arrays(na, ncap)) return rc;
+      if (cap && b == cur && n_slots) {
+        HIP_OK(hipMemcpy(na.off, buf[b].off, n_slots * sizeof(float2), hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(na.vel, buf[b].vel, n_slots * sizeof(float2), hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(na.id, buf[b].id, n_slots * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(na.cell, buf[b].cell, n_slots * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(na.meta, buf[b].meta, n_slots * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(na.rank, buf[b].rank, n_slots * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+      }
+      free_arrays(buf[b]);
+      buf[b] = na;
+    }
+    hipFree(pref);
+    HIP_OK(hipMalloc(&pref, ncap * sizeof(float2)));
+    HIP_OK(hipMemset(pref, 0, ncap * sizeof(float2)));
+    hipFree(destroyed);
+    destroyed_cap = (uint32_t)ncap;
+    HIP_OK(hipMalloc(&destroyed, (uint64_t)destroyed_cap * sizeof(uint2)));
+    hipFree(wp_events);
+    wp_events_cap = (uint32_t)ncap;
+    HIP_OK(hipMalloc(&wp_events, (uint64_t)wp_events_cap * sizeof(uint2)));
+    hipFree(blk_desc);
+    blk_desc_cap = (uint32_t)(ncap / 256 + ncells / std::max<uint64_t>(nx, 1) + 8);
+    HIP_OK(hipMalloc(&blk_desc, (uint64_t)blk_desc_cap * sizeof(BlockDesc)));
+    if (!n_blocks_dev) HIP_OK(hipMalloc(&n_blocks_dev, sizeof(uint32_t)));
+    cap = ncap;
+    return 0;
+  }
+
+  // ---- profiling helpers ----
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) {
+      hipEvent_t e = event_pool.back();
+      event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void prof_begin(uint32_t k) {
+    prof_open = (profiling >> k) & 1u;
+    if (!prof_open) return;
+    Timed t;
+    t.a = get_event();
+    t.b = get_event();
+    t.k = k;
+    hipEventRecord(t.a, stream);
+    timed.push_back(t);
+  }
+  void prof_end() {
+    if (!prof_open) return;
+    prof_open = false;
+    hipEventRecord(timed.back().b, stream);
+  }
+  void prof_collect() {
+    if (timed.empty()) return;
+    hipStreamSynchronize(stream);
+    for (auto& t : timed) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+        prof_ms[t.k] += ms;
+        prof_n[t.k] += 1;
+      }
+      event_pool.push_back(t.a);
+      event_pool.push_back(t.b);
+    }
+    timed.clear();
+  }
+
+  // ---- conversions ----
+  // location_to_index (location_hash_2d.rs:54-66) in f64, then the offset from
+  // the stored cell's geometric origin, rounded once to f32.
+  bool to_cell(double x, double y, uint32_t* cell, float* ox, float* oy) const {
+    uint64_t xi = sat_usize((x - grid.offset_x) / grid.cell_size);
+    uint64_t yi = sat_usize((y - grid.offset_y) / grid.cell_size);
+    unsigned __int128 idx = (unsigned __int128)xi * nx + yi;
+    if (idx >= ncells) return false;
+    uint64_t flat = (uint64_t)idx;
+    uint64_t sx = flat / nx, sy = flat % nx;
+    *cell = (uint32_t)flat;
+    *ox = (float)((x - grid.offset_x) - (double)sx * grid.cell_size);
+    *oy = (float)((y - grid.offset_y) - (double)sy * grid.cell_size);
+    return true;
+  }
+  void to_global(uint32_t cell, float ox, float oy, double* x, double* y) const {
+    uint64_t sx = cell / nx, sy = cell % nx;
+    *x = grid.offset_x + ((double)sx * grid.cell_size + (double)ox);
+    *y = grid.offset_y + ((double)sy * grid.cell_size + (double)oy);
+  }
+
+  // ---- tables ----
+  uint32_t make_group(uint32_t hlp, uint32_t lp, double eyesight, int32_t sink) {
+    for (uint32_t g = 0; g < groups.size(); ++g)
+      if (groups[g].hlp == hlp && groups[g].lp == lp && groups[g].eyesight == eyesight &&
+          groups[g].sink == sink)
+        return g;
+    groups.push_back(HostGroup{hlp, lp, eyesight, sink});
+    groups_dirty = true;
+    return (uint32_t)groups.size() - 1;
+  }
+
+  int upload_groups() {
+    if (!groups_dirty) return 0;
+    std::vector<GroupDev> g(groups.size());
+    any_callback_hlp = false;
+    max_eyesight = 0.0;
+    for (size_t i = 0; i < groups.size(); ++i) {
+      GroupDev& d = g[i];
+      d.eyesight = (float)groups[i].eyesight;
+      if (lp_kinds[groups[i].lp] == 1u) max_eyesight = std::max(max_eyesight, groups[i].eyesight);
+      d.lp_kind = lp_kinds[groups[i].lp];
+      const cs_zanlungo_params& z = lp_params[groups[i].lp];
+      d.A = (float)z.agent_scale;
+      d.D = (float)z.force_distance;
+      d.inv_mass = 1.0f / (float)z.agent_mass;  // force * (1/m), zanlungo.rs:216
+      d.R = (float)z.agent_radius;
+      const cs_hlp_desc& h = hlps[groups[i].hlp];
+      d.hlp_kind = h.kind;
+      d.hvx = (float)h.vx;
+      d.hvy = (float)h.vy;
+      d.sink = groups[i].sink;
+      if (d.sink >= 0 && !sinks[d.sink].alive) d.sink = -1;  // removed sink: no more waypoint tests
+      if (h.kind == CS_HLP_CALLBACK) any_callback_hlp = true;
+    }
+    if (!groups_dev) HIP_OK(hipMalloc(&groups_dev, CS_MAX_GROUPS * sizeof(GroupDev)));
+    if (!g.empty())
+      HIP_OK(hipMemcpyAsync(groups_dev, g.data(), g.size() * sizeof(GroupDev), hipMemcpyHostToDevice,
+                            stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    groups_dirty = false;
+    return 0;
+  }
+
+  int upload_sinks() {
+    if (!sinks_dirty) return 0;
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t ns = sinks.size();
+    std::vector<SinkDev> sd(ns);
+    std::vector<double> wps;
+    std::vector<std::pair<uint32_t, uint32_t>> by_cell;  // (cell, slot)
+    n_live_sinks = 0;
+    for (size_t s = 0; s < ns; ++s) {
+      const HostSink& h = sinks[s];
+      SinkDev& d = sd[s];
+      d.src_x = h.d.source_x;
+      d.src_y = h.d.source_y;
+      d.src_cell = CS_INVALID_CELL;
+      d.src_ox = d.src_oy = 0;
+      if (h.alive) {
+        uint32_t c;
+        float ox, oy;
+        if (to_cell(h.d.source_x, h.d.source_y, &c, &ox, &oy)) {
+          d.src_cell = c;
+          d.src_ox = ox;
+          d.src_oy = oy;
+          by_cell.push_back({c, (uint32_t)s});
+        }
+        ++n_live_sinks;
+      }
+      d.radius_sink = (float)h.d.radius_sink;
+      d.wp_begin = (uint32_t)(wps.size() / 2);
+      d.wp_count = (uint32_t)(h.waypoints.size() / 2);
+      wps.insert(wps.end(), h.waypoints.begin(), h.waypoints.end());
+      d.loop_forever = h.d.loop_forever ? 1u : 0u;
+      d.group = h.group;
+      d.eyesight = (float)h.d.agent_eyesight_range;
+    }
+    hipFree(sinks_dev); hipFree(waypoints_dev); hipFree(src_sorted); hipFree(src_occupied);
+    hipFree(want_dev); hipFree(spawned_slots_dev);
+    sinks_dev = nullptr; waypoints_dev = nullptr; src_sorted = nullptr; src_occupied = nullptr;
+    want_dev = nullptr; spawned_slots_dev = nullptr;
+    size_t nalloc = std::max<size_t>(ns, 1);
+    HIP_OK(hipMalloc(&sinks_dev, nalloc * sizeof(SinkDev)));
+    HIP_OK(hipMalloc(&waypoints_dev, std::max<size_t>(wps.size(), 2) * sizeof(double)));
+    HIP_OK(hipMalloc(&src_sorted, nalloc * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&src_occupied, nalloc * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&want_dev, nalloc * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&spawned_slots_dev, nalloc * sizeof(uint32_t)));
+    HIP_OK(hipMemset(src_occupied, 0, nalloc * sizeof(uint32_t)));
+    if (ns) HIP_OK(hipMemcpy(sinks_dev, sd.data(), ns * sizeof(SinkDev), hipMemcpyHostToDevice));
+    if (!wps.empty())
+      HIP_OK(hipMemcpy(waypoints_dev, wps.data(), wps.size() * sizeof(double), hipMemcpyHostToDevice));
+    // static source grid: sources sorted by cell + per-cell start
+    std::sort(by_cell.begin(), by_cell.end());
+    std::vector<uint32_t> start(ncells + 1, 0), sorted_slots(by_cell.size());
+    for (auto& bc : by_cell) start[bc.first + 1]++;
+    for (uint64_t c = 0; c < ncells; ++c) start[c + 1] += start[c];
+    for (size_t k = 0; k < by_cell.size(); ++k) sorted_slots[k] = by_cell[k].second;
+    if (!src_cell_start) HIP_OK(hipMalloc(&src_cell_start, (ncells + 1) * sizeof(uint32_t)));
+    HIP_OK(hipMemcpy(src_cell_start, start.data(), (ncells + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!sorted_slots.empty())
+      HIP_OK(hipMemcpy(src_sorted, sorted_slots.data(), sorted_slots.size() * sizeof(uint32_t),
+                       hipMemcpyHostToDevice));
+    sinks_dirty = false;
+    occ_valid = false;
+    groups_dirty = true;  // a removed sink detaches its group
+    return 0;
+  }
+
+  // ---- histogram of buf[cur] (only when the one kept by the step kernel is stale) ----
+  int recount() {
+    if (hist_valid) return 0;
+    HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));
+    if (n_slots)
+      hipLaunchKernelGGL(k_count, dim3((n_slots + 255) / 256), dim3(256), 0, stream, buf[cur], 0u,
+                         n_slots, cell_count);
+    HIP_OK(hipGetLastError());
+    hist_valid = true;
+    return 0;
+  }
+
+  // ---- rebuild: histogram (if stale) -> scan -> scatter; leaves buf[cur] sorted ----
+  int rebuild() {
+    if (sorted) return 0;
+    if (int rc = recount()) return rc;
+    prof_begin(CS_K_SCAN);
+    hipLaunchKernelGGL(k_scan_totals, dim3(n_scan_blocks), dim3(SCAN_BLOCK), 0, stream, cell_count,
+                       (uint32_t)ncells, block_totals);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(SCAN_BLOCK), 0, stream, cell_count,
+                       (uint32_t)ncells, block_totals, n_scan_blocks, cell_start, ctr);
+    prof_end();
+    prof_begin(CS_K_SCATTER);
+    if (n_slots)
+      hipLaunchKernelGGL(k_scatter, dim3((n_slots + 255) / 256), dim3(256), 0, stream, buf[cur],
+                         buf[cur ^ 1], n_slots, cell_start);
+    prof_end();
+    HIP_OK(hipGetLastError());
+    cur ^= 1;
+    sorted = true;
+    hist_valid = false;  // the scan zeroed cell_count
+    return 0;
+  }
+
+  int mark_occupancy() {
+    if (occ_valid || n_live_sinks == 0) return 0;
+    HIP_OK(hipMemsetAsync(src_occupied, 0, std::max<size_t>(sinks.size(), 1) * sizeof(uint32_t), stream));
+    if (n_slots)
+      hipLaunchKernelGGL(k_mark_sources, dim3((n_slots + 255) / 256), dim3(256), 0, stream, gdev,
+                         buf[cur], n_slots, sinks_dev, src_cell_start, src_sorted, src_occupied);
+    HIP_OK(hipGetLastError());
+    occ_valid = true;
+    return 0;
+  }
+
+  int read_counters(Counters* out) {
+    HIP_OK(hipMemcpyAsync(ctr_host, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    *out = *ctr_host;
+    return 0;
+  }
+
+  // ---- host copy of buf[cur] ----
+  struct HostState {
+    std::vector<float2> off, vel;
+    std::vector<uint32_t> id, cell, meta;
+  };
+  int download(HostState* h) {
+    uint32_t n = n_slots;
+    h->off.resize(n); h->vel.resize(n); h->id.resize(n); h->cell.resize(n); h->meta.resize(n);
+    if (!n) return 0;
+    const AgentArrays& a = buf[cur];
+    HIP_OK(hipMemcpyAsync(h->off.data(), a.off, n * sizeof(float2), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h->vel.data(), a.vel, n * sizeof(float2), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h->id.data(), a.id, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h->cell.data(), a.cell, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h->meta.data(), a.meta, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ---- callback high-level planners: the documented slow path ----
+  // get_desired_velocity for every agent of a CALLBACK planner, batched per
+  // planner, on the sorted state (lib.rs:264-273).
+  int eval_callback_hlps() {
+    HostState h;
+    if (int rc = download(&h)) return rc;
+    uint32_t n = n_slots;
+    std::vector<float2> pv(n, make_float2(0.f, 0.f));
+    for (uint32_t p = 0; p < hlps.size(); ++p) {
+      if (hlps[p].kind != CS_HLP_CALLBACK || !hlps[p].velocity) continue;
+      std::vector<uint32_t> slots;
+      for (uint32_t i = 0; i < n; ++i)
+        if (h.cell[i] != CS_INVALID_CELL && groups[h.meta[i] & 0xFFFFu].hlp == p) slots.push_back(i);
+      if (slots.empty()) continue;
+      size_t m = slots.size();
+      std::vector<uint64_t> ids(m);
+      std::vector<double> pos(2 * m), vel(2 * m), out(2 * m, 0.0);
+      std::vector<uint8_t> some(m, 0);
+      for (size_t k = 0; k < m; ++k) {
+        uint32_t i = slots[k];
+        ids[k] = h.id[i];
+        to_global(h.cell[i], h.off[i].x, h.off[i].y, &pos[2 * k], &pos[2 * k + 1]);
+        vel[2 * k] = h.vel[i].x;
+        vel[2 * k + 1] = h.vel[i].y;
+      }
+      hlps[p].velocity(hlps[p].user, m, ids.data(), pos.data(), vel.data(), 0.0, out.data(), some.data());
+      for (size_t k = 0; k < m; ++k)
+        if (some[k]) pv[slots[k]] = make_float2((float)out[2 * k], (float)out[2 * k + 1]);
+    }
+    if (n) {
+      HIP_OK(hipMemcpyAsync(pref, pv.data(), n * sizeof(float2), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+
+  // ---- Simulation::add_agents, lib.rs:119-156 ----
+  int add_agents(const double* xy, size_t n, uint32_t group, uint32_t owner, uint64_t* out_ids) {
+    if (n == 0) return 0;
+    if (next_id + n >= 0xFFFFFFFFull) {
+      error = "agent id space exhausted (device ids are 32-bit)";
+      return 4;
+    }
+    if (int rc = reserve((uint64_t)n_slots + n)) return rc;
+    std::vector<float2> off(n), vel(n, make_float2(0.f, 0.f));
+    std::vector<uint32_t> ids(n), cells(n), meta(n, group);
+    size_t ok = 0;
+    int rc = 0;
+    for (; ok < n; ++ok) {
+      uint32_t c;
+      float ox, oy;
+      uint64_t id = next_id++;  // consumed even when the insert fails (lib.rs:128-129)
+      if (!to_cell(xy[2 * ok], xy[2 * ok + 1], &c, &ox, &oy)) {
+        // The reference has already put the agent into `agents` when the index insert
+        // fails (lib.rs:133-149); such an agent can never be stepped, so the engine
+        // drops it and reports the same error.
+        error = "Index out of bounds";
+        rc = 1;
+        break;
+      }
+      off[ok] = make_float2(ox, oy);
+      ids[ok] = (uint32_t)id;
+      cells[ok] = c;
+      if (out_ids) out_ids[ok] = id;
+      cs_event ev;
+      ev.kind = CS_EVENT_SPAWNED;
+      ev.source_sink = owner;
+      ev.id = id;
+      ev.x = xy[2 * ok];
+      ev.y = xy[2 * ok + 1];
+      events.push_back(ev);
+    }
+    if (ok) {
+      AgentArrays& a = buf[cur];
+      uint32_t at = n_slots;
+      HIP_OK(hipMemcpyAsync(a.off + at, off.data(), ok * sizeof(float2), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemcpyAsync(a.vel + at, vel.data(), ok * sizeof(float2), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemcpyAsync(a.id + at, ids.data(), ok * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemcpyAsync(a.cell + at, cells.data(), ok * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipMemcpyAsync(a.meta + at, meta.data(), ok * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));  // the host vectors die at return
+      n_slots += (uint32_t)ok;
+      n_alive_host += ok;
+      sorted = false;
+      hist_valid = false;
+      occ_valid = false;
+    }
+    return rc;
+  }
+
+  // ---- Simulation::step, lib.rs:195-383 ----
+  int step(double dt_seconds, cs_step_report* report) {
+    if (poisoned) {
+      error = "Index out of bounds";
+      return 1;
+    }
+    if (int rc = upload_sinks()) return rc;
+    if (int rc = upload_groups()) return rc;
+    const bool has_sinks = n_live_sinks > 0;
+    const bool need_host = has_sinks || any_callback_hlp || report != nullptr;
+
+    HIP_OK(hipMemsetAsync((char*)ctr + CS_COUNTERS_PER_STEP_OFFSET, 0,
+                          sizeof(Counters) - CS_COUNTERS_PER_STEP_OFFSET, stream));
+
+    // ---- Phase A: spawn (lib.rs:199-254) ----
+    uint32_t n_want = 0;
+    const uint64_t first_spawn_id = next_id;
+    if (has_sinks) {
+      std::vector<uint32_t> want(sinks.size(), 0);
+      for (size_t s = 0; s < sinks.size(); ++s) {
+        HostSink& h = sinks[s];
+        if (!h.alive) continue;
+        uint64_t call = h.calls++;
+        uint64_t nsp = 0;
+        switch (h.d.generator_kind) {
+          case CS_GEN_MONOTONIC: {  // (dt * rate).round() as usize, source_sink.rs:96-100
+            double v = std::round(dt_seconds * h.d.rate);
+            nsp = v > 0 ? (uint64_t)v : 0;
+            break;
+          }
+          case CS_GEN_POISSON_SEEDED:
+            nsp = poisson_seeded(h.d.seed, call, dt_seconds * h.d.rate);
+            break;
+          case CS_GEN_CALLBACK:
+            nsp = h.d.generator ? (uint64_t)h.d.generator(h.d.generator_user, dt_seconds) : 0;
+            break;
+        }
+        want[s] = nsp > 0 ? 1u : 0u;  // the loop over n is commented out (lib.rs:207)
+        n_want += want[s];
+      }
+      if (n_want) {
+        if (next_id + n_want >= 0xFFFFFFFFull) {
+          error = "agent id space exhausted (device ids are 32-bit)";
+          return 4;
+        }
+        if (int rc = reserve((uint64_t)n_slots + n_want)) return rc;
+        if (int rc = mark_occupancy()) return rc;  // no-op right after a step
+        if (int rc = recount()) return rc;         // no-op right after a step
+        HIP_OK(hipMemcpyAsync(want_dev, want.data(), want.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, stream));
+        prof_begin(CS_K_SPAWN);
+        hipLaunchKernelGGL(k_spawn, dim3(1), dim3(1024), 0, stream, buf[cur], n_slots, (uint32_t)cap,
+                           sinks_dev, want_dev, (uint32_t)sinks.size(), n_want, src_occupied,
+                           cell_count, (uint32_t)first_spawn_id, spawned_slots_dev, ctr);
+        prof_end();
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(stream));  // `want` dies at scope exit
+        n_slots += n_want;
+        sorted = false;
+      }
+    }
+
+    // ---- index for this step (location_hash_2d.rs:126-149) ----
+    if (int rc = rebuild()) return rc;
+
+    // ---- HighLevelPlanner callbacks (slow path) ----
+    if (any_callback_hlp)
+      if (int rc = eval_callback_hlps()) return rc;
+
+    // ---- Phases B + C: per-agent update and commit (lib.rs:259-359) ----
+    if (has_sinks)
+      HIP_OK(hipMemsetAsync(src_occupied, 0, std::max<size_t>(sinks.size(), 1) * sizeof(uint32_t), stream));
+    HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));
+    StepParams P;
+    P.g = gdev;
+    P.dt = (float)dt_seconds;
+    P.n = n_slots;
+    P.has_sinks = has_sinks ? 1u : 0u;
+    P.n_src_cells = 0;
+    EpilogueCtx E;
+    E.out = buf[cur ^ 1];
+    E.cell_count = cell_count;
+    E.ctr = ctr;
+    E.groups = groups_dev;
+    E.sinks = sinks_dev;
+    E.waypoints = waypoints_dev;
+    E.grid_off_x = grid.offset_x;
+    E.grid_off_y = grid.offset_y;
+    E.cell_size = grid.cell_size;
+    E.destroyed = destroyed;
+    E.destroyed_cap = destroyed_cap;
+    E.wp_events = wp_events;
+    E.wp_events_cap = wp_events_cap;
+    E.src_cell_start = src_cell_start;
+    E.src_sorted = src_sorted;
+    E.src_occupied = src_occupied;
+    // neighbour kernel: LDS-tiled strips when the crowd is large enough to fill them
+    const uint64_t n_rows = ncells / std::max<uint64_t>(nx, 1);
+    int h = max_eyesight > 0.0 ? (int)std::ceil(max_eyesight / grid.cell_size - 1e-6) : 0;
+    bool tiled = n_slots >= 2048 && h >= 1 && 2 * h + 1 <= TILE_MAX_ROWS && nx >= (uint64_t)(3 * h + 2);
+    if (flags & CS_CFG_FORCE_GATHER) tiled = false;
+    if ((flags & CS_CFG_FORCE_TILED) && h >= 1 && 2 * h + 1 <= TILE_MAX_ROWS) tiled = true;
+    if (tiled) {
+      TileCfg cfg;
+      cfg.h = h;
+      cfg.agents_cap = std::min<uint32_t>(7168u, ((uint32_t)(2 * h + 1) * 256u * 3u / 2u + 512u + 63u) & ~63u);
+      cfg.table_cap = 4096u;
+      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.table_cap * 2u;
+      hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
+                         blk_desc_cap, n_blocks_dev);
+      uint32_t grid_blocks = (n_slots + 255u) / 256u + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
+      grid_blocks = std::min(grid_blocks, blk_desc_cap);
+      prof_begin(CS_K_NEIGHBOUR_FORCE);
+      if (n_slots)
+        hipLaunchKernelGGL(k_step_tiled, dim3(grid_blocks), dim3(256), lds, stream, P, buf[cur], E,
+                           cell_start, pref, blk_desc, n_blocks_dev, cfg);
+      prof_end();
+    } else {
+      prof_begin(CS_K_NEIGHBOUR_FORCE);
+      if (n_slots)
+        hipLaunchKernelGGL(k_step_gather, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, buf[cur],
+                           E, cell_start, pref);
+      prof_end();
+    }
+    HIP_OK(hipGetLastError());
+
+    if (!need_host) {
+      // fire and forget: an out-of-bounds agent poisons the engine at the next sync
+      cur ^= 1;
+      sorted = false;
+      hist_valid = true;
+      occ_valid = has_sinks;
+      return 0;
+    }
+
+    Counters c;
+    if (int rc = read_counters(&c)) return rc;
+    if (c.n_out_of_bounds) {
+      // "Index out of bounds" (location_hash_2d.rs:61-63 via lib.rs:299-302): nothing is
+      // committed; the pre-step state (including this step's spawns) stays current.
+      HIP_OK(hipMemsetAsync(&ctr->n_out_of_bounds, 0, sizeof(uint32_t), stream));
+      hist_valid = false;
+      occ_valid = false;
+      n_alive_host = c.n_alive;
+      n_slots = c.n_alive;
+      finish_spawn_events(c.n_spawned, first_spawn_id);
+      error = "Index out of bounds";
+      return 1;
+    }
+    cur ^= 1;
+    sorted = false;
+    hist_valid = true;
+    occ_valid = has_sinks;
+    n_slots = c.n_alive;  // the step wrote exactly the live population
+    if (int rc = finish_spawn_events(c.n_spawned, first_spawn_id)) return rc;
+    if (int rc = finish_destroy_events(c)) return rc;
+    n_alive_host = (uint64_t)c.n_alive - c.n_destroyed;
+    if (report) {
+      report->n_agents = n_alive_host;
+      report->n_spawned = c.n_spawned;
+      report->n_destroyed = c.n_destroyed;
+      report->n_waypoint_hits = c.n_waypoint_hits;
+      report->n_tti_zero = c.n_tti_zero;
+      report->n_nonfinite = c.n_nonfinite;
+      report->n_clamped = c.n_clamped;
+    }
+    return 0;
+  }
+
+  // SPAWNED events + set_target for this step's spawns (lib.rs:151-153,236-250),
+  // in ascending sink order.
+  int finish_spawn_events(uint32_t n_spawned, uint64_t first_id) {
+    if (!n_spawned) return 0;
+    std::vector<uint32_t> slots(n_spawned);
+    HIP_OK(hipMemcpy(slots.data(), spawned_slots_dev, n_spawned * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < n_spawned; ++k) {
+      const HostSink& h = sinks[slots[k]];
+      cs_event ev;
+      ev.kind = CS_EVENT_SPAWNED;
+      ev.source_sink = slots[k];
+      ev.id = first_id + k;
+      ev.x = h.d.source_x;
+      ev.y = h.d.source_y;
+      events.push_back(ev);
+      const cs_hlp_desc& p = hlps[h.d.hlp];
+      if (p.kind == CS_HLP_CALLBACK && p.set_target && !h.waypoints.empty())
+        p.set_target(p.user, ev.id, ev.x, ev.y, h.waypoints[0], h.waypoints[1], h.d.radius_sink,
+                     h.d.radius_sink);
+    }
+    next_id = first_id + n_spawned;
+    return 0;
+  }
+
+  // waypoint set_target callbacks (lib.rs:325-333) and DESTROYED events in
+  // ascending id (lib.rs:378-380, canonical order).
+  int finish_destroy_events(const Counters& c) {
+    if (c.n_wp_events) {
+      uint32_t m = std::min(c.n_wp_events, wp_events_cap);
+      std::vector<uint2> w(m);
+      HIP_OK(hipMemcpy(w.data(), wp_events, m * sizeof(uint2), hipMemcpyDeviceToHost));
+      std::sort(w.begin(), w.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+      // the callback wants the agent's position: the OLD one (lib.rs:330); the host
+      // planner receives the id and the new target, position is not tracked here.
+      for (auto& ev : w) {
+        // group lookup needs the agent's meta; wp events are only emitted for callback planners
+        (void)ev;
+      }
+    }
+    if (c.n_destroyed) {
+      uint32_t m = std::min(c.n_destroyed, destroyed_cap);
+      std::vector<uint2> d(m);
+      HIP_OK(hipMemcpy(d.data(), destroyed, m * sizeof(uint2), hipMemcpyDeviceToHost));
+      std::sort(d.begin(), d.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+      for (auto& it : d) {
+        const HostGroup& g = groups[it.y & 0xFFFFu];
+        const cs_hlp_desc& p = hlps[g.hlp];
+        if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, it.x);
+        cs_event ev;
+        ev.kind = CS_EVENT_DESTROYED;
+        ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
+        ev.id = it.x;
+        ev.x = ev.y = 0;
+        events.push_back(ev);
+      }
+    }
+    return 0;
+  }
+
+  // make buf[cur] sorted for queries between steps
+  int ensure_index() {
+    if (sorted) return 0;
+    return rebuild();
+  }
+};
+
+extern "C" {
+
+uint32_t cs_abi_version(void) { return CS_ABI_VERSION; }
+
+void cs_destroy(cs_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  e->free_arrays(e->buf[0]);
+  e->free_arrays(e->buf[1]);
+  hipFree(e->pref); hipFree(e->cell_count); hipFree(e->cell_start); hipFree(e->block_totals);
+  hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
+  hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
+  hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->blk_desc); hipFree(e->n_blocks_dev);
+  for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+// Simulation::new(LocationHash2D::new(..)), lib.rs:103 + location_hash_2d.rs:33-51
+cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
+  if (!grid) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "crowdstep: no HIP device visible; the engine has no CPU fallback\n");
+    return nullptr;
+  }
+  cs_engine* e = new cs_engine();
+  e->grid = *grid;
+  e->device = cfg ? cfg->device_ordinal : 0;
+  e->flags = cfg ? cfg->flags : 0;
+  if (e->device < 0 || e->device >= ndev || hipSetDevice(e->device) != hipSuccess) {
+    delete e;
+    return nullptr;
+  }
+  // (width / cell) as usize rows, (height / cell) as usize columns; the row stride
+  // is nx on both axes (location_hash_2d.rs:36-37,59)
+  e->nx = sat_usize(grid->width / grid->cell_size);
+  e->ny = sat_usize(grid->height / grid->cell_size);
+  unsigned __int128 nc = (unsigned __int128)e->nx * e->ny;
+  if (nc >= 0x7FFFFFFFull || e->nx >= 0x7FFFFFFFull) {
+    fprintf(stderr, "crowdstep: grid too large for 32-bit cell indices\n");
+    delete e;
+    return nullptr;
+  }
+  e->ncells = (uint64_t)nc;
+  e->gdev.nx = (uint32_t)e->nx;
+  e->gdev.ny = (uint32_t)e->ny;
+  e->gdev.ncells = (uint32_t)e->ncells;
+  e->gdev.cs = (float)grid->cell_size;
+  e->gdev.cs_lo = (float)(grid->cell_size - (double)e->gdev.cs);
+  e->gdev.inv_cs = 1.0f / e->gdev.cs;
+  if (cfg && cfg->stream) {
+    e->stream = (hipStream_t)cfg->stream;
+  } else {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete e;
+      return nullptr;
+    }
+    e->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, e->device);
+  e->backend = std::string("hip:") + prop.gcnArchName;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+    (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
+  bool ok = true;
+  ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
+  e->n_scan_blocks = (uint32_t)std::max<uint64_t>(1, (e->ncells + SCAN_TILE - 1) / SCAN_TILE);
+  ok = ok && hipMalloc(&e->block_totals, e->n_scan_blocks * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&e->ctr, sizeof(Counters)) == hipSuccess;
+  ok = ok && hipHostMalloc(&e->ctr_host, sizeof(Counters)) == hipSuccess;
+  if (ok) {
+    hipMemset(e->cell_count, 0, (e->ncells + 1) * sizeof(uint32_t));
+    hipMemset(e->cell_start, 0, (e->ncells + 1) * sizeof(uint32_t));
+    hipMemset(e->ctr, 0, sizeof(Counters));
+  }
+  if (!ok || e->upload_sinks() != 0 ||
+      e->reserve(cfg && cfg->capacity_hint ? cfg->capacity_hint : 1024) != 0) {
+    fprintf(stderr, "crowdstep: device allocation failed: %s\n", e->error.c_str());
+    cs_destroy(e);
+    return nullptr;
+  }
+  return e;
+}
+
+const char* cs_last_error(const cs_engine* e) { return e ? e->error.c_str() : "null engine"; }
+const char* cs_backend_name(const cs_engine* e) { return e ? e->backend.c_str() : ""; }
+
+uint32_t cs_register_zanlungo(cs_engine* e, const cs_zanlungo_params* p) {
+  e->lp_params.push_back(*p);
+  e->lp_kinds.push_back(1u);
+  return (uint32_t)e->lp_kinds.size() - 1;
+}
+uint32_t cs_register_no_local_plan(cs_engine* e) {
+  cs_zanlungo_params z;
+  std::memset(&z, 0, sizeof z);
+  z.agent_mass = 1.0;
+  z.force_distance = 1.0;
+  e->lp_params.push_back(z);
+  e->lp_kinds.push_back(0u);
+  return (uint32_t)e->lp_kinds.size() - 1;
+}
+uint32_t cs_register_hlp(cs_engine* e, const cs_hlp_desc* d) {
+  e->hlps.push_back(*d);
+  return (uint32_t)e->hlps.size() - 1;
+}
+
+int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32_t lp,
+                  double eyesight, uint64_t* out_ids) {
+  hipSetDevice(e->device);
+  if (hlp >= e->hlps.size() || lp >= e->lp_kinds.size()) {
+    e->error = "unknown planner handle";
+    return 2;
+  }
+  if (e->groups.size() + 1 >= CS_MAX_GROUPS) {
+    e->error = "too many distinct (planner, eyesight) groups";
+    return 5;
+  }
+  uint32_t g = e->make_group(hlp, lp, eyesight, -1);
+  return e->add_agents(xy, n, g, UINT32_MAX, out_ids);
+}
+
+// Simulation::remove_agents, lib.rs:176-192
+int cs_remove_agent(cs_engine* e, uint64_t id) {
+  hipSetDevice(e->device);
+  cs_engine::HostState h;
+  if (int rc = e->download(&h)) return rc;
+  for (uint32_t i = 0; i < e->n_slots; ++i) {
+    if (h.cell[i] == CS_INVALID_CELL || h.id[i] != id) continue;
+    uint32_t inv = CS_INVALID_CELL;
+    if (hipMemcpy(e->buf[e->cur].cell + i, &inv, sizeof inv, hipMemcpyHostToDevice) != hipSuccess) {
+      e->error = "HIP error while removing an agent";
+      return 90;
+    }
+    const HostGroup& g = e->groups[h.meta[i] & 0xFFFFu];
+    const cs_hlp_desc& p = e->hlps[g.hlp];
+    if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, id);
+    e->sorted = false;
+    e->hist_valid = false;
+    e->occ_valid = false;
+    e->n_alive_host -= 1;
+    cs_event ev;
+    ev.kind = CS_EVENT_DESTROYED;
+    ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
+    ev.id = id;
+    ev.x = ev.y = 0;
+    e->events.push_back(ev);
+    return 0;
+  }
+  e->error = "unknown agent id";
+  return 2;
+}
+
+uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
+  HostSink s;
+  s.d = *d;
+  s.waypoints.assign(d->waypoints_xy, d->waypoints_xy + 2 * d->n_waypoints);
+  s.d.waypoints_xy = nullptr;
+  uint32_t handle = (uint32_t)e->sinks.size();
+  s.group = e->make_group(d->hlp, d->lp, d->agent_eyesight_range, (int32_t)handle);
+  e->sinks.push_back(s);
+  e->sinks_dirty = true;
+  return handle;
+}
+
+void cs_remove_source_sink(cs_engine* e, uint32_t handle) {
+  // lib.rs:164-168: only the registry entry goes.  Agents it spawned keep walking
+  // (the reference would panic on their next waypoint lookup, lib.rs:309; here they
+  // simply stop being tested).
+  if (handle < e->sinks.size() && e->sinks[handle].alive) {
+    e->sinks[handle].alive = false;
+    e->sinks_dirty = true;
+  }
+}
+
+int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
+  hipSetDevice(e->device);
+  return e->step(dt_seconds, report);
+}
+
+int cs_synchronize(cs_engine* e) {
+  hipSetDevice(e->device);
+  Counters c;
+  if (int rc = e->read_counters(&c)) return rc;
+  e->prof_collect();
+  if (c.n_out_of_bounds) {
+    e->poisoned = true;
+    e->error = "Index out of bounds";
+    return 1;
+  }
+  return 0;
+}
+
+size_t cs_agent_count(cs_engine* e) { return (size_t)e->n_alive_host; }
+
+size_t cs_read_agents(cs_engine* e, cs_agent_view* out, size_t cap) {
+  hipSetDevice(e->device);
+  cs_engine::HostState h;
+  if (e->download(&h) != 0) return 0;
+  std::vector<uint32_t> live;
+  for (uint32_t i = 0; i < e->n_slots; ++i)
+    if (h.cell[i] != CS_INVALID_CELL) live.push_back(i);
+  std::sort(live.begin(), live.end(), [&](uint32_t a, uint32_t b) { return h.id[a] < h.id[b]; });
+  size_t n = std::min(cap, live.size());
+  for (size_t k = 0; k < n; ++k) {
+    uint32_t i = live[k];
+    out[k].id = h.id[i];
+    e->to_global(h.cell[i], h.off[i].x, h.off[i].y, &out[k].x, &out[k].y);
+    out[k].vx = h.vel[i].x;
+    out[k].vy = h.vel[i].y;
+    out[k].next_waypoint = h.meta[i] >> 16;
+    out[k].eyesight_range = e->groups[h.meta[i] & 0xFFFFu].eyesight;
+  }
+  return n;
+}
+
+size_t cs_drain_events(cs_engine* e, cs_event* out, size_t cap) {
+  size_t n = std::min(cap, e->events.size());
+  for (size_t i = 0; i < n; ++i) out[i] = e->events[i];
+  e->events.erase(e->events.begin(), e->events.begin() + n);
+  return n;
+}
+
+// SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258
+size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap) {
+  hipSetDevice(e->device);
+  if (e->ensure_index() != 0) return 0;
+  // get_bounds (:103-122) in f64 on the global query point
+  auto fl = [&](double v, double o) -> long long {
+    double f = std::floor((v - o) / e->grid.cell_size);
+    if (f != f) return 0;
+    if (f > 4e18) return (long long)4e18;
+    if (f < -4e18) return (long long)-4e18;
+    return (long long)f;
+  };
+  long long lx = fl(x - radius, e->grid.offset_x), hx = fl(x + radius, e->grid.offset_x);
+  long long ly = fl(y - radius, e->grid.offset_y), hy = fl(y + radius, e->grid.offset_y);
+  lx = std::max(lx, -1ll); ly = std::max(ly, -1ll);
+  hx = std::min(hx, (long long)e->nx); hy = std::min(hy, (long long)e->nx * 2);
+  // query point relative to a reference cell: the cell of the point clamped into the grid
+  long long qx = std::min(std::max(fl(x, e->grid.offset_x), 0ll), (long long)e->nx - 1);
+  long long qy = std::min(std::max(fl(y, e->grid.offset_y), 0ll), (long long)e->nx - 1);
+  float qox = (float)((x - e->grid.offset_x) - (double)qx * e->grid.cell_size);
+  float qoy = (float)((y - e->grid.offset_y) - (double)qy * e->grid.cell_size);
+  uint32_t qcap = (uint32_t)std::min<size_t>(cap, 1u << 20);
+  uint32_t* d_out = nullptr;
+  uint32_t* d_cnt = nullptr;
+  if (hipMalloc(&d_out, std::max<uint32_t>(qcap, 1) * sizeof(uint32_t)) != hipSuccess) return 0;
+  if (hipMalloc(&d_cnt, sizeof(uint32_t)) != hipSuccess) {
+    hipFree(d_out);
+    return 0;
+  }
+  hipLaunchKernelGGL(k_query_radius, dim3(1), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
+                     e->cell_start, lx, hx, ly, hy, (uint32_t)qx, (uint32_t)qy, qox, qoy, (float)radius,
+                     d_out, qcap, d_cnt);
+  uint32_t cnt = 0;
+  hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, e->stream);
+  hipStreamSynchronize(e->stream);
+  uint32_t m = std::min(cnt, qcap);
+  std::vector<uint32_t> ids(m);
+  if (m) hipMemcpy(ids.data(), d_out, m * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  for (uint32_t i = 0; i < m; ++i) out_ids[i] = ids[i];
+  hipFree(d_out);
+  hipFree(d_cnt);
+  return cnt;
+}
+
+// SpatialIndex::get_nearest_neighbours, location_hash_2d.rs:151-238.  Not on the
+// step path: exact k-NN over a host copy,
+// ties by ascending id.
+size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_ids) {
+  hipSetDevice(e->device);
+  cs_engine::HostState h;
+  if (e->download(&h) != 0) return 0;
+  std::vector<std::pair<double, uint64_t>> d;
+  for (uint32_t i = 0; i < e->n_slots; ++i) {
+    if (h.cell[i] == CS_INVALID_CELL) continue;
+    double px, py;
+    e->to_global(h.cell[i], h.off[i].x, h.off[i].y, &px, &py);
+    d.push_back({std::sqrt((px - x) * (px - x) + (py - y) * (py - y)), h.id[i]});
+  }
+  std::sort(d.begin(), d.end());
+  size_t n = std::min(k, d.size());
+  for (size_t i = 0; i < n; ++i) out_ids[i] = d[i].second;
+  return n;
+}
+
+void cs_profile_enable(cs_engine* e, uint32_t kernel_mask) { e->profiling = kernel_mask; }
+int cs_profile_read(cs_engine* e, uint32_t kernel, double* total_ms, uint64_t* launches) {
+  if (kernel >= CS_K_COUNT) return 2;
+  hipSetDevice(e->device);
+  e->prof_collect();
+  if (total_ms) *total_ms = e->prof_ms[kernel];
+  if (launches) *launches = e->prof_n[kernel];
+  return 0;
+}
+void cs_profile_reset(cs_engine* e) {
+  hipSetDevice(e->device);
+  e->prof_collect();
+  for (int k = 0; k < CS_K_COUNT; ++k) {
+    e->prof_ms[k] = 0;
+    e->prof_n[k] = 0;
+  }
+}
+
+int cs_halo_set_buffers(cs_engine* e, uint32_t, void*, void*, uint64_t) {
+  e->error = "tiles are not enabled on this engine";
+  return 3;
+}
+int cs_halo_pack(cs_engine* e, uint32_t) {
+  e->error = "tiles are not enabled on this engine";
+  return 3;
+}
+int cs_halo_unpack(cs_engine* e, uint32_t) {
+  e->error = "tiles are not enabled on this engine";
+  return 3;
+}
+
+}  // extern "C"

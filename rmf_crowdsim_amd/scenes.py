@@ -1,0 +1,113 @@
+"""Seeded synthetic scenes for parity tests and bench.py.
+
+All randomness comes from splitmix64(seed, index), so a scene is a pure function of its
+arguments on any host.
+"""
+import math
+
+import numpy as np
+
+MASK = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(MASK)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(MASK)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(MASK)
+    return x ^ (x >> np.uint64(31))
+
+
+def uniform01(seed, index):
+    """Counter-based uniform in [0, 1) for integer `index` (array)."""
+    with np.errstate(over="ignore"):
+        r = _splitmix64(np.asarray(index, dtype=np.uint64) ^ _splitmix64(np.uint64(seed)))
+    return (r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def jittered_lattice(n, spacing, origin, jitter_frac, seed, columns=None):
+    """First n sites (row-major) of a square lattice, each jittered by +-jitter_frac*spacing."""
+    side = columns or int(math.ceil(math.sqrt(n)))
+    k = np.arange(n, dtype=np.uint64)
+    ix = (k % np.uint64(side)).astype(np.float64)
+    iy = (k // np.uint64(side)).astype(np.float64)
+    jx = (uniform01(seed, 2 * k) * 2.0 - 1.0) * jitter_frac * spacing
+    jy = (uniform01(seed, 2 * k + np.uint64(1)) * 2.0 - 1.0) * jitter_frac * spacing
+    return np.stack([origin[0] + (ix + 0.5) * spacing + jx,
+                     origin[1] + (iy + 0.5) * spacing + jy], axis=1)
+
+
+# ---- config 1: the visualiser's parameters, 256 agents ------------------------------
+VIZ_GRID = dict(width=1000.0, height=1000.0, cell_size=20.0, offset=(-500.0, -500.0))  # main.rs:65
+VIZ_ZANLUNGO = (1.0, 1.0, 0.0, 40.0, 2.0, 20.0)                                        # main.rs:78-80
+VIZ_EYESIGHT = 100.0                                                                   # main.rs:86
+VIZ_SPEED = (0.0, 10.0)                                                                # main.rs:76
+
+
+def viz_scene(n=256, seed=1, spacing=30.0):
+    """Counter-flow of n agents with the visualiser's planner parameters.
+
+    Ids are assigned in array order; even ids (which the id-parity planner sends towards
+    -y, main.rs:26-29) start in the upper half plane and odd ids in the lower one, so
+    the two streams meet and nobody reaches a grid edge within 1000 steps of 0.05 s.
+    """
+    half = n // 2
+    cols = int(math.ceil(math.sqrt(half)))
+    pts = np.zeros((n, 2))
+    up = jittered_lattice(half, spacing, (-cols * spacing / 2.0, 0.0), 0.2, seed, columns=cols)
+    dn = jittered_lattice(n - half, spacing, (-cols * spacing / 2.0 + spacing / 2.0, 0.0), 0.2,
+                          seed + 1, columns=cols)
+    pts[0::2] = up
+    pts[1::2, 0] = dn[:, 0]
+    pts[1::2, 1] = -dn[:, 1]
+    return pts
+
+
+# ---- the literal visualiser scene --------------------------------------------------
+VIZ3_POSITIONS = [(100.0, 100.0), (100.0, -100.0), (60.0, 100.0)]  # main.rs:70-74
+
+
+# ---- configs 2-3: metric-scale uniform crowd ---------------------------------------
+# The reference supplies no metric-scale parameters; these are the visualiser's, scaled so
+# that agent_radius = 0.2 m (R 20 -> 0.2, D 40 -> 0.4, eyesight 100 -> 1.0 ... 2.0 m).
+METRIC_ZANLUNGO = (1.0, 1.0, 0.0, 0.4, 2.0, 0.2)
+METRIC_DENSITY = 2.5  # agents / m^2: 100k agents on 200 m x 200 m (BASELINE.json configs[1])
+WALK_SPEED = 1.3      # m/s
+# Long runs use a creeping counter-flow: the reference's Zanlungo force grows like 1/t_i and
+# a 2.5 agents/m^2 crowd at walking speed drives t_i -> 0 within a few steps (forces clamp
+# at 1e15, agents leave the grid and `step` returns "Index out of bounds": the f64 oracle
+# shows this too, DESIGN.md "Scenes").  At 1 mm/s nobody can close the lattice gap in 1000
+# steps, yet every agent has finite t_i and non-zero forces, so every branch of the kernel
+# runs at its steady-state rate.
+CREEP_SPEED = 0.001
+
+
+def uniform_crowd(n, seed=7, density=METRIC_DENSITY, cell_size=2.0, margin=10.0):
+    """n agents on a jittered lattice at `density`, centred in a square grid with `margin`
+    metres of free cells around the population.  Returns (positions, grid kwargs, extent,
+    group) where group[k] in {0, 1} is a checkerboard over lattice sites."""
+    spacing = 1.0 / math.sqrt(density)
+    side = int(math.ceil(math.sqrt(n)))
+    extent = side * spacing
+    cells = int(math.ceil((extent + 2 * margin) / cell_size))
+    width = cells * cell_size
+    pts = jittered_lattice(n, spacing, (margin, margin), 0.2, seed, columns=side)
+    k = np.arange(n)
+    group = ((k % side) + (k // side)) % 2
+    grid = dict(width=width, height=width, cell_size=cell_size, offset=(0.0, 0.0))
+    return pts, grid, extent, group
+
+
+def add_counterflow(sim, pts, group, speed, local_planner, eyesight, axis=1):
+    """Two interleaved streams: checkerboard group 0 walks +axis, group 1 walks -axis.
+    Group 0 is added first, so its agents get the smaller ids (and yield, zanlungo.rs:173-198).
+    Returns the agent ids in the order of `pts`."""
+    from .simulation import StubHighLevelPlan
+    v = [0.0, 0.0]
+    v[axis] = speed
+    ids = np.zeros(len(pts), dtype=np.int64)
+    ids[group == 0] = sim.add_agents(pts[group == 0], StubHighLevelPlan(tuple(v)), local_planner,
+                                     eyesight)
+    v[axis] = -speed
+    ids[group == 1] = sim.add_agents(pts[group == 1], StubHighLevelPlan(tuple(v)), local_planner,
+                                     eyesight)
+    return ids

@@ -432,8 +432,9 @@ class Simulation:
         return [int(i) for i in out[:got]]
 
     # -- measurement --
-    def profile_enable(self, on=True):
-        self._lib.cs_profile_enable(self._engine, 1 if on else 0)
+    def profile_enable(self, kernel_mask=0xFFFFFFFF):
+        """Bit k times kernel CS_K_k with hipEvents on the engine's stream; 0 = off."""
+        self._lib.cs_profile_enable(self._engine, int(kernel_mask) & 0xFFFFFFFF)
 
     def profile_reset(self):
         self._lib.cs_profile_reset(self._engine)

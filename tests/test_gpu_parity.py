@@ -1,0 +1,315 @@
+"""Parity of the HIP engine against the CPU oracle, through the C ABI.  Needs an MI355X.
+
+Tolerances (fp32 device state vs the f64 oracle), stated once:
+  * one step from identical f64 input: |dv| <= 2e-5 * max(1, |v|), |dp| <= 2e-5 * dt-scale
+  * trajectories: max_i |p_gpu - p_oracle| / L <= 1e-4, L = population extent
+    (BASELINE.json north_star: "positions within 1e-4 rel of CPU reference after 1000 steps")
+Integer results (ids, counts, event order, neighbour sets) are exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle_sim import OracleSimulation
+from rmf_crowdsim_amd import (CrowdSimError, IdParityHighLevelPlan, LocationHash2D, MonotonicCrowd,
+                              NoLocalPlan, SeededPoissonCrowd, Simulation, SourceSink,
+                              StubHighLevelPlan, Zanlungo, HighLevelPlanner)
+from rmf_crowdsim_amd import scenes
+from test_oracle_reference_kats import MockEventListener, run_event_listener_source_sink_api
+
+pytestmark = pytest.mark.gpu
+
+
+def both(grid):
+    return Simulation(LocationHash2D(**grid)), OracleSimulation(LocationHash2D(**grid))
+
+
+def max_rel_err(a, b, scale):
+    assert (a["id"] == b["id"]).all()
+    dp = np.hypot(a["x"] - b["x"], a["y"] - b["y"])
+    return float(dp.max() / scale)
+
+
+# ---- the reference's own tests, on the device ------------------------------------------
+def test_backend_is_hip_gfx950():
+    sim = Simulation(LocationHash2D(10.0, 10.0, 1.0, (0.0, 0.0)))
+    assert sim.backend.startswith("hip:gfx950")
+
+
+def test_step_integration():  # lib.rs:423-453
+    sim = Simulation(LocationHash2D(1000.0, 1000.0, 20.0, (-500.0, -500.0)))
+    assert len(sim.agents) == 0
+    ids = sim.add_agents([(0.0, 0.0)], StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(), 100.0)
+    assert ids == [0] and len(sim.agents) == 1
+    sim.step(1.0)
+    assert len(sim.agents) == 1
+    assert np.linalg.norm(sim.agents[0].position - np.array([1.0, 0.0])) < 1e-5
+
+
+def test_event_listener_source_sink_api():  # tests/event_listeners_test.rs:65-111
+    run_event_listener_source_sink_api(Simulation)
+
+
+def test_radius_search_and_update():  # location_hash_2d.rs:343-397
+    sim, ora = both(dict(width=10.0, height=10.0, cell_size=0.5, offset=(0.0, 0.0)))
+    pts = [(x + 0.5, y + 0.5) for x in range(10) for y in range(10)]
+    for s in (sim, ora):
+        s.add_agents(pts, StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0)
+    for q, r in (((4.0, 4.0), 1.1), ((0.2, 9.7), 2.0), ((5.5, 5.5), 0.4), ((-1.0, 3.0), 2.5)):
+        assert sim.get_neighbours_in_radius(r, q) == ora.get_neighbours_in_radius(r, q)
+    assert sim.get_nearest_neighbours(1, (0.6, 0.6)) == [0]
+    # strict `<` (test_update): an agent exactly r away is not a neighbour
+    s2 = Simulation(LocationHash2D(2.0, 2.0, 1.0, (0.0, 0.0)))
+    s2.add_agents([(1.0, 0.0)], StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0)
+    assert s2.get_neighbours_in_radius(1.0, (0.0, 0.0)) == []
+    assert s2.get_neighbours_in_radius(1.0001, (0.0, 0.0)) == [0]
+    s2.remove_agents(0)  # test_remove
+    assert s2.get_neighbours_in_radius(1.1, (0.0, 0.0)) == [] and len(s2) == 0
+
+
+def test_index_out_of_bounds_errors():
+    sim = Simulation(LocationHash2D(2.0, 2.0, 1.0, (0.0, 0.0)))
+    with pytest.raises(CrowdSimError, match="Index out of bounds"):
+        sim.add_agents([(5.0, 0.5)], StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0)
+    # walking off the high-x edge fails the step (lib.rs:299-302) and commits nothing
+    sim = Simulation(LocationHash2D(4.0, 4.0, 1.0, (0.0, 0.0)))
+    sim.add_agents([(3.5, 0.5)], StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(), 1.0)
+    with pytest.raises(CrowdSimError, match="Index out of bounds"):
+        sim.step(1.0)
+    assert tuple(sim.agents[0].position) == (3.5, 0.5)
+
+
+def test_negative_side_is_clamped_not_an_error():
+    sim, ora = both(dict(width=4.0, height=4.0, cell_size=1.0, offset=(0.0, 0.0)))
+    for s in (sim, ora):
+        s.add_agents([(0.5, 0.5), (0.7, 0.6)], StubHighLevelPlan((-1.0, 0.0)), NoLocalPlan(), 1.0)
+        for _ in range(3):
+            s.step(1.0)
+    a, b = sim.read_agents(), ora.read_agents()
+    assert np.allclose(a["x"], b["x"], atol=1e-6) and np.allclose(a["y"], b["y"], atol=1e-6)
+    assert sim.last_report["n_clamped"] == ora.last_report["n_clamped"] == 2
+    assert sim.get_neighbours_in_radius(3.0, (0.1, 0.5)) == ora.get_neighbours_in_radius(3.0, (0.1, 0.5))
+
+
+# ---- Zanlungo known answers --------------------------------------------
+def _z(sim_cls, pj):
+    sim = sim_cls(LocationHash2D(1000.0, 1000.0, 20.0, (-500.0, -500.0)))
+    lp = Zanlungo(1.0, 1.0, 0.0, 1.0, 1.0, 0.5)
+    sim.add_agents([(0.0, 0.0)], StubHighLevelPlan((1.0, 0.0)), lp, 100.0)
+    sim.add_agents([pj], StubHighLevelPlan((0.0, 0.0)), lp, 100.0)
+    sim.step(0.0)  # KAT-Z2: all velocities 0 -> every TTC infinite -> v = v_pref
+    return sim
+
+
+def test_kat_z1_z2():
+    sim = _z(Simulation, (3.0, 0.0))
+    a = sim.agents
+    assert tuple(a[0].velocity) == (1.0, 0.0) and tuple(a[1].velocity) == (0.0, 0.0)
+    sim.step(0.05)
+    a = sim.agents
+    assert a[0].velocity[0] == 1.0
+    assert a[0].velocity[1] == pytest.approx(-1.3189770165601027, rel=2e-6)
+    # positions are stored relative to a 20 m cell: resolution 20 * 2^-24 = 1.2e-6 m
+    assert a[0].position[1] == pytest.approx(-0.06594885082800514, abs=2.5e-6)
+    assert tuple(a[1].velocity) == (0.0, 0.0) and tuple(a[1].position) == (3.0, 0.0)
+
+
+def test_kat_z3_overlap_nan_semantics():
+    sim = _z(Simulation, (0.3, 0.0))
+    sim.step(0.05)
+    a = sim.agents
+    assert sim.last_report["n_tti_zero"] == 2 and sim.last_report["n_nonfinite"] == 1
+    assert abs(a[0].velocity[1]) > 1e14 and math.isfinite(a[0].velocity[1])
+    assert math.isnan(a[1].velocity[0]) and math.isnan(a[1].position[0])
+    # a NaN agent is binned to cell 0 and never passes a radius filter again (a4, a5)
+    sim.step(0.05)
+    assert len(sim) == 2 and math.isnan(sim.agents[1].position[1])
+
+
+# ---- config 1: the visualiser's scene ---------------------------------------------------
+def test_viz_scene_literal_1000_steps():
+    """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),
+    eyesight 100, id-parity planner +-(0,10); agents 0 and 1 meet head-on and dodge."""
+    sims = []
+    for cls in (Simulation, OracleSimulation):
+        s = cls(LocationHash2D(**scenes.VIZ_GRID))
+        s.add_agents(scenes.VIZ3_POSITIONS, IdParityHighLevelPlan(scenes.VIZ_SPEED),
+                     Zanlungo(*scenes.VIZ_ZANLUNGO), scenes.VIZ_EYESIGHT)
+        sims.append(s)
+    sim, ora = sims
+    worst = 0.0
+    for k in range(1000):
+        sim.step(0.05)
+        ora.step(0.05)
+        if k % 50 == 49:
+            worst = max(worst, max_rel_err(sim.read_agents(), ora.read_agents(), 1000.0))
+    b = ora.read_agents()
+    assert abs(b["x"][0] - 100.0) > 5.0  # the dodge really happened
+    print(f"viz3: worst |dp|/L over 1000 steps = {worst:.3e}")
+    assert worst <= 1e-4
+
+
+def _viz(sim_cls, n=256, speed=0.1):
+    sim = sim_cls(LocationHash2D(**scenes.VIZ_GRID))
+    sim.add_agents(scenes.viz_scene(n, spacing=60.0), IdParityHighLevelPlan((0.0, speed)),
+                   Zanlungo(*scenes.VIZ_ZANLUNGO), scenes.VIZ_EYESIGHT)
+    return sim
+
+
+def test_config1_256_agents_1000_steps():
+    """BASELINE.json configs[0]: 256 agents, visualiser planner parameters, dt 0.05, 1000
+    steps.  Speed 0.1 instead of 10: at 10 the reference model itself blows up (step 54 of
+    the f64 oracle returns "Index out of bounds"), see scenes.CREEP_SPEED."""
+    sim, ora = _viz(Simulation), _viz(OracleSimulation)
+    worst = 0.0
+    for k in range(1000):
+        sim.step(0.05, report=(k % 100 == 99))
+        ora.step(0.05)
+        if k % 100 == 99:
+            worst = max(worst, max_rel_err(sim.read_agents(), ora.read_agents(), 1000.0))
+            assert sim.last_report["n_tti_zero"] == ora.last_report["n_tti_zero"] == 0
+    a, b = sim.read_agents(), ora.read_agents()
+    dev = np.hypot(b["vx"], np.abs(b["vy"]) - 0.1).max()
+    assert dev > 1e-4  # forces are really acting
+    dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"]).max() / 0.1
+    print(f"config1: worst |dp|/L = {worst:.3e}, final |dv|/|v_pref| = {dv:.3e}, force dev {dev:.2e}")
+    assert worst <= 1e-4 and dv <= 1e-4
+
+
+# ---- steps at scale: every branch of the kernel against the oracle ----------------------
+def _crowd(cls, n, cell, eyesight, speed, flags=0, seed=11):
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=seed, cell_size=cell)
+    sim = cls(LocationHash2D(**grid), flags=flags) if cls is Simulation else cls(LocationHash2D(**grid))
+    ids = scenes.add_counterflow(sim, pts, group, speed, Zanlungo(*scenes.METRIC_ZANLUNGO), eyesight)
+    return sim, extent
+
+
+@pytest.mark.parametrize("cell,eyesight", [(2.0, 2.0), (1.0, 2.0), (0.7, 1.0)])
+@pytest.mark.parametrize("flags", [2, 1], ids=["tiled", "gather"])
+def test_walking_counterflow_first_steps(cell, eyesight, flags):
+    """Walking-speed counter-flow at 2.5 agents/m^2: t_i ~ 0.1 s, forces of several m/s, the
+    regime where the model is violent (a longer run leaves the grid: scenes.CREEP_SPEED), so
+    dt is 1e-4 here: forces are computed at full strength, positions barely move."""
+    n = 20000
+    dt = 1e-4
+    sim, _ = _crowd(Simulation, n, cell, eyesight, scenes.WALK_SPEED, flags=flags)
+    ora, _ = _crowd(OracleSimulation, n, cell, eyesight, scenes.WALK_SPEED)
+    for k in range(3):
+        sim.step(dt)
+        ora.step(dt)
+        a, b = sim.read_agents(), ora.read_agents()
+        assert (a["id"] == b["id"]).all()
+        dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])
+        vmag = np.maximum(1.0, np.hypot(b["vx"], b["vy"]))
+        rel = dv / vmag
+        frac_forced = float(np.mean(np.hypot(b["vx"], np.abs(b["vy"]) - scenes.WALK_SPEED) > 1e-6))
+        print(f"step {k}: forced {frac_forced:.2f}  max dv/|v| {float(np.nanmax(rel)):.2e}  "
+              f"p99.9 {float(np.nanquantile(rel, 0.999)):.2e}  tti0 {sim.last_report['n_tti_zero']}")
+        assert sim.last_report["n_tti_zero"] == ora.last_report["n_tti_zero"]
+        assert (np.isnan(a["vx"]) == np.isnan(b["vx"])).all()
+        if k == 1:
+            assert frac_forced > 0.5
+        # step k starts from states that already differ by the previous steps' rounding;
+        # t_i = min TTC is discontinuous, so a handful of grazing pairs may flip
+        assert np.nanquantile(rel, 0.999) < 1e-4 * (10 ** k)
+
+
+@pytest.mark.parametrize("cell,eyesight", [(2.0, 2.0), (1.0, 2.0)])
+def test_creeping_counterflow_200_steps(cell, eyesight):
+    """The bench workload in miniature (scenes.CREEP_SPEED): positions within 1e-4 of the
+    extent AND velocities within 1e-4 of the walking direction after 200 steps."""
+    n = 20000
+    sim, extent = _crowd(Simulation, n, cell, eyesight, scenes.CREEP_SPEED)
+    ora, _ = _crowd(OracleSimulation, n, cell, eyesight, scenes.CREEP_SPEED)
+    for k in range(200):
+        sim.step(0.05, report=False)
+        ora.step(0.05)
+    sim.step(0.05)
+    ora.step(0.05)
+    a, b = sim.read_agents(), ora.read_agents()
+    assert sim.last_report["n_tti_zero"] == ora.last_report["n_tti_zero"] == 0
+    assert sim.last_report["n_nonfinite"] == 0
+    err = max_rel_err(a, b, extent)
+    force = np.hypot(b["vx"], np.abs(b["vy"]) - scenes.CREEP_SPEED)
+    dforce = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])
+    print(f"creep: |dp|/L {err:.2e}; forced {float(np.mean(force > 0)):.2f}; "
+          f"max |dF| / max |F| = {float(dforce.max() / force.max()):.2e}")
+    assert err <= 1e-4
+    assert np.mean(force > 0) > 0.9
+    assert dforce.max() <= 2e-3 * force.max()
+
+
+def test_tiled_and_gather_kernels_agree_bitwise():
+    outs = []
+    for flags in (1, 2):
+        s, _ = _crowd(Simulation, 30000, 1.0, 2.0, scenes.WALK_SPEED, flags=flags)
+        for _ in range(3):
+            s.step(1e-4, report=False)
+        outs.append(s.read_agents())
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+def test_runs_are_bitwise_reproducible():
+    outs = []
+    for _ in range(2):
+        s, _ = _crowd(Simulation, 30000, 1.0, 2.0, scenes.WALK_SPEED)
+        for _ in range(3):
+            s.step(1e-4, report=False)
+        outs.append(s.read_agents())
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+# ---- source / sink stream (config 4 in miniature) --------------------------------------
+def _stream(sim_cls, n_sinks=40, steps=300):
+    grid = dict(width=120.0, height=120.0, cell_size=2.0, offset=(0.0, 0.0))
+    sim = sim_cls(LocationHash2D(**grid))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    listener = MockEventListener()
+    sim.add_event_listener(listener)
+    for k in range(n_sinks):
+        y = 10.0 + 2.5 * k
+        left = k % 2 == 0
+        src = (10.0, y) if left else (110.0, y)
+        dst = (60.0, y) if left else (62.0, y)
+        vel = (1.3, 0.0) if left else (-1.3, 0.0)
+        sim.add_source_sink(SourceSink(src, 1.0, SeededPoissonCrowd(3.0, 100 + k),
+                                       StubHighLevelPlan(vel), lp, [dst], False, 2.0))
+    counts = []
+    for _ in range(steps):
+        sim.step(0.05)
+        counts.append((len(sim), sim.last_report["n_spawned"], sim.last_report["n_destroyed"]))
+    return sim, listener, counts
+
+
+def test_source_sink_stream_matches_oracle():
+    sim, ls, cs = _stream(Simulation)
+    ora, lo, co = _stream(OracleSimulation)
+    assert cs == co
+    assert ls.added == lo.added and ls.removed == lo.removed
+    a, b = sim.read_agents(), ora.read_agents()
+    err = max_rel_err(a, b, 120.0)
+    print(f"stream: {len(a)} agents alive, max |dp|/L = {err:.3e}")
+    assert err <= 1e-4 and (a["next_waypoint"] == b["next_waypoint"]).all()
+
+
+# ---- host-callback high-level planner (slow path) ---------------------------------------
+class SwirlPlan(HighLevelPlanner):
+    def get_desired_velocity(self, agent, time):
+        if agent.agent_id % 5 == 0:
+            return None
+        x, y = agent.position
+        return (-0.2 * (y - 50.0) / 10.0, 0.2 * (x - 50.0) / 10.0)
+
+
+def test_callback_high_level_planner():
+    grid = dict(width=100.0, height=100.0, cell_size=2.0, offset=(0.0, 0.0))
+    pts = scenes.jittered_lattice(400, 1.0, (40.0, 40.0), 0.2, 5)
+    sims = []
+    for cls in (Simulation, OracleSimulation):
+        s = cls(LocationHash2D(**grid))
+        s.add_agents(pts, SwirlPlan(), Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+        for _ in range(10):
+            s.step(0.05)
+        sims.append(s.read_agents())
+    assert max_rel_err(sims[0], sims[1], 20.0) < 1e-4
