@@ -96,71 +96,97 @@ struct AgentArrays {
 __device__ __forceinline__ float f_inf() { return __builtin_huge_valf(); }
 __device__ __forceinline__ float f_nan() { return __builtin_nanf(""); }
 
+// ---------------------------------------------------------------------------
+// Arithmetic of the neighbour pass.  One definition, used by both neighbour
+// kernels, so their results are bitwise equal.  Divisions, square roots and the
+// exponential use the 1-ulp hardware forms (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 /
+// v_exp_f32): the IEEE-exact expansions cost ~10 VALU each and this kernel is
+// VALU-issue bound (profiles/), while the fp32 tolerance of the path is 1e-4.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // Zanlungo::time_to_collision, zanlungo.rs:49-74 (collision distance is R, not 2R).
+// With bh = b/2 the quadratic reads t = (-bh -+ sqrt(bh^2 - a c)) / a: the same values as
+// the reference's (-b -+ sqrt(b^2 - 4ac)) / 2a, the factors of two being exact.  For a > 0
+// the roots are ordered (t0 <= t1), which folds the reference's case analysis into
+//   disc < 0 -> inf;  t0 > 0 -> t0;  t1 > 0 -> (t0 < 0 ? 0 : t1);  else inf.
 // f32 has 1/8 of f64's exponent range: |rel_vel|^2 underflows near 1e-19 m/s where the
 // reference's f64 does not, and a flushed `a` with b != 0 would read as "colliding now"
 // (t0 = -inf, t1 = +inf -> 0).  Tiny relative velocities are therefore scaled by 2^48
-// first (t(s*rv) = t(rv)/s exactly), and what still underflows takes the a -> 0 limit of
-// the same quadratic, which is what f64 computes there.
-__device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float R2) {
+// first (t(s*rv) = t(rv)/s exactly); what still underflows takes the a -> 0 limit of
+// the same quadratic, which is what f64 computes there.  d2 = |rp|^2.
+__device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float d2,
+                                         float R2) {
   float tscale = 1.0f;
   if (fmaxf(fabsf(rvx), fabsf(rvy)) < 1e-12f) {
     rvx *= 0x1p48f;
     rvy *= 0x1p48f;
     tscale = 0x1p48f;
   }
-  float a = rvx * rvx + rvy * rvy;
-  float b = 2.0f * (rvx * rpx + rvy * rpy);
-  float c = (rpx * rpx + rpy * rpy) - R2;
+  const float a = __builtin_fmaf(rvx, rvx, rvy * rvy);
+  const float bh = __builtin_fmaf(rvx, rpx, rvy * rpy);
+  const float c = d2 - R2;
   if (a < 1e-30f) {
-    if (b == 0.0f) return f_inf();      // equal velocities: 0/0 = NaN fails every comparison
-    if (c < 0.0f) return 0.0f;          // already inside R: t0 < 0 < t1
-    return b < 0.0f ? (-c / b) * tscale : f_inf();
+    if (bh == 0.0f) return f_inf();  // equal velocities: 0/0 = NaN fails every comparison
+    if (c < 0.0f) return 0.0f;       // already inside R: t0 < 0 < t1
+    return bh < 0.0f ? (-c / (2.0f * bh)) * tscale : f_inf();
   }
-  float disc = b * b - 4.0f * a * c;
-  if (disc < 0.0f) return f_inf();
-  float root = sqrtf(disc);
-  float den = 2.0f * a;
-  float t0 = (-b - root) / den;
-  float t1 = (-b + root) / den;
-  if ((t0 < 0.0f && t1 > 0.0f) || (t1 < 0.0f && t0 > 0.0f)) return 0.0f;
-  if (t0 < t1 && t0 > 0.0f) return t0 * tscale;
-  if (t1 > 0.0f) return t1 * tscale;
-  return f_inf();
+  const float disc = __builtin_fmaf(bh, bh, -(a * c));
+  const float root = fast_sqrt(disc);
+  const float ia = fast_rcp(a) * tscale;
+  const float t0 = (-bh - root) * ia;
+  const float t1 = (-bh + root) * ia;
+  float t = (t1 > 0.0f) ? ((t0 < 0.0f) ? 0.0f : t1) : f_inf();
+  t = (t0 > 0.0f) ? t0 : t;
+  return (disc < 0.0f) ? f_inf() : t;
+}
+
+// What every force term of one agent shares (zanlungo.rs:93-170 with weight = 2):
+//   fut = v_i * t_i,  mag = min(1e15, 2 * A * |v_i| / t_i),  k = log2(e) / D
+struct ForceCtx {
+  float vix, viy, futx, futy, mag, two_R, k_exp;
+};
+
+__device__ __forceinline__ ForceCtx make_force_ctx(float vix, float viy, float T, const GroupDev& grp) {
+  ForceCtx c;
+  c.vix = vix;
+  c.viy = viy;
+  c.futx = vix * T;
+  c.futy = viy * T;
+  // weight * agent_scale * |my_vel - other_vel| / t_i with weight 2, other_vel 0; once per agent,
+  // so the exact division is kept (t_i == 0 -> +inf -> clamped, zanlungo.rs:165-167)
+  float mag = 2.0f * grp.A * sqrtf(__builtin_fmaf(vix, vix, viy * viy)) / T;
+  c.mag = (mag >= 1e15f) ? 1e15f : mag;
+  c.two_R = grp.R * 2.0f;
+  c.k_exp = 1.44269504088896341f / grp.D;
+  return c;
 }
 
 // Force on agent i from a neighbour j with the LARGER id (weight = 2 branch of
-// compute_agent_force, zanlungo.rs:93-170, with right_of_way_vel :173-198 and
-// slerp :23-28 folded for the state the reference actually produces: a
-// neighbour's preferred_vel is always (0,0) (lib.rs:140,261,271: it is set on
-// the per-iteration clone only), so other_vel = v_j + 1*(0 - v_j) = 0 and the
-// "stationary" branch :119-125 is the live one; slerp(1, d, perp, s) =
-// d*(sin(0)/s) + perp*(sin(asin s)/s) = d*0 + perp*1 for s > 0 and NaN for s == 0,
-// and the following normalize() removes the factor sin(asin s)/s = 1 +- 1 ulp).
-//   rp = p_j - p_i, futx/futy = v_i * T, mag = min(1e15, 2*A*|v_i| / T)
-__device__ __forceinline__ void zanlungo_forward_force(float rpx, float rpy, float vix, float viy,
-                                                       float futx, float futy, float mag,
-                                                       float two_R, float D, float& fx,
-                                                       float& fy) {
-  float dx = futx - rpx, dy = futy - rpy;  // (p_i + v_i T) - (p_j + 0 T)
-  float dist = sqrtf(dx * dx + dy * dy);
+// compute_agent_force, zanlungo.rs:93-170, with right_of_way_vel :173-198 and slerp :23-28
+// folded for the state the reference actually produces: a neighbour's preferred_vel is
+// always (0,0) (lib.rs:140,261,271: it is set on the per-iteration clone only), so
+// other_vel = v_j + 1*(0 - v_j) = 0 and the "stationary" branch :119-125 is the live one;
+// slerp(1, d, perp, s) = d*(sin(0)/s) + perp*(sin(asin s)/s) = d*0 + perp*1 for s > 0 and NaN
+// for s == 0, and the normalize() that follows removes the factor sin(asin s)/s = 1 +- 1 ulp).
+// |perp| = |rp|, so the unit vector is perp * rsqrt(d2).   rp = p_j - p_i, d2 = |rp|^2.
+__device__ __forceinline__ void zanlungo_forward_force(float rpx, float rpy, float d2,
+                                                       const ForceCtx& c, float& fx, float& fy) {
+  const float dx = c.futx - rpx, dy = c.futy - rpy;  // (p_i + v_i T) - (p_j + 0 T)
+  const float dist = fast_sqrt(__builtin_fmaf(dx, dx, dy * dy));
   float px = rpy, py = -rpx;  // perp of q = p_i - p_j = -rp: (-q.y, q.x)
-  if (px * vix + py * viy < 0.0f) {
-    px = -px;
-    py = -py;
-  }
-  float s = fabsf(px * dy - py * dx);
+  const bool flip = __builtin_fmaf(px, c.vix, py * c.viy) < 0.0f;
+  px = flip ? -px : px;
+  py = flip ? -py : py;
+  const float s = fabsf(__builtin_fmaf(px, dy, -(py * dx)));
   // s > 1 clamps to 1 and drops out; s == 0 or NaN poisons the direction (0/0)
-  if (!(s > 0.0f)) {
-    px = f_nan();
-    py = f_nan();
-  }
-  float en = sqrtf(px * px + py * py);
-  float nx = px / en, ny = py / en;
-  float surface = dist - two_R;
-  float scale = mag * expf(-surface / D);
-  fx += nx * scale;
-  fy += ny * scale;
+  const float inv_n = (s > 0.0f) ? fast_rsq(d2) : f_nan();
+  const float scale = c.mag * fast_exp2((c.two_R - dist) * c.k_exp) * inv_n;
+  fx = __builtin_fmaf(px, scale, fx);
+  fy = __builtin_fmaf(py, scale, fy);
 }
 
 struct StepParams {
@@ -574,7 +600,8 @@ struct TiledSrc {
   }
 };
 
-// Returns the new velocity w = u + F/m of agent `o` (zanlungo.rs:201-217).
+// Returns the new velocity w = u + F/m of agent `o` (zanlungo.rs:201-217).  Generic form:
+// every candidate is processed where it is found.  Used by the gather kernel.
 template <class Src>
 __device__ __forceinline__ void zanlungo_velocity(const Own& o, const GroupDev& grp, const GridDev& g,
                                                   long long lx, long long hx, long long ly,
@@ -586,19 +613,21 @@ __device__ __forceinline__ void zanlungo_velocity(const Own& o, const GroupDev& 
   float T = f_inf();
   uint32_t n_back = 0;
   for (long long x = lx; x <= hx; ++x) {
-    const float shx = (float)(x - (long long)o.gx) * g.cs;
+    // own offset as seen from cell (x, y): p_j - p_i = off_j - (off_i - shift)
+    const float oix = __builtin_fmaf(-(float)(x - (long long)o.gx), g.cs, o.off.x);
     for (long long y = ly; y <= hy; ++y) {
       uint32_t b, e;
       if (!src.cell(x, y, b, e)) continue;
-      const float shy = (float)(y - (long long)o.gy) * g.cs;
+      const float oiy = __builtin_fmaf(-(float)(y - (long long)o.gy), g.cs, o.off.y);
       for (uint32_t j = b; j < e; ++j) {
         if (src.is_self(j)) continue;  // lib.rs:284
         const float2 oj = src.off(j, x, y);
-        const float rpx = shx + (oj.x - o.off.x), rpy = shy + (oj.y - o.off.y);  // p_j - p_i
-        if (!(rpx * rpx + rpy * rpy < r2)) continue;  // strict `<`, location_hash_2d.rs:251
+        const float rpx = oj.x - oix, rpy = oj.y - oiy;  // p_j - p_i
+        const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
+        if (!(d2 < r2)) continue;  // strict `<`, location_hash_2d.rs:251
         const float2 vj = src.vel(j);
-        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, R2);
-        if (t < T) T = t;
+        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, d2, R2);
+        T = (t < T) ? t : T;
         n_back += (src.id(j) < o.id) ? 1u : 0u;
       }
     }
@@ -606,27 +635,23 @@ __device__ __forceinline__ void zanlungo_velocity(const Own& o, const GroupDev& 
   tti_zero = (T == 0.0f);
   float fx = 0.0f, fy = 0.0f;
   if (T != f_inf()) {  // zanlungo.rs:211
-    // compute_agent_force for the neighbours that have right of way (larger id)
-    const float futx = o.v.x * T, futy = o.v.y * T;
-    // weight * agent_scale * |my_vel - other_vel| / t_i with weight 2, other_vel 0
-    float mag = 2.0f * grp.A * sqrtf(o.v.x * o.v.x + o.v.y * o.v.y) / T;
-    if (mag >= 1e15f) mag = 1e15f;  // zanlungo.rs:165-167
-    const float two_R = grp.R * 2.0f;
+    const ForceCtx fc = make_force_ctx(o.v.x, o.v.y, T, grp);
     for (long long x = lx; x <= hx; ++x) {
-      const float shx = (float)(x - (long long)o.gx) * g.cs;
+      const float oix = __builtin_fmaf(-(float)(x - (long long)o.gx), g.cs, o.off.x);
       for (long long y = ly; y <= hy; ++y) {
         uint32_t b, e;
         if (!src.cell(x, y, b, e)) continue;
-        const float shy = (float)(y - (long long)o.gy) * g.cs;
+        const float oiy = __builtin_fmaf(-(float)(y - (long long)o.gy), g.cs, o.off.y);
         uint32_t last = 0;
         bool have_last = false;
         for (uint32_t k = 0; k < e - b; ++k) {
           const uint32_t j = src.ordered(b, e, k, last, have_last);
           if (!(src.id(j) > o.id)) continue;  // self and smaller ids: weight 0
           const float2 oj = src.off(j, x, y);
-          const float rpx = shx + (oj.x - o.off.x), rpy = shy + (oj.y - o.off.y);
-          if (!(rpx * rpx + rpy * rpy < r2)) continue;
-          zanlungo_forward_force(rpx, rpy, o.v.x, o.v.y, futx, futy, mag, two_R, grp.D, fx, fy);
+          const float rpx = oj.x - oix, rpy = oj.y - oiy;
+          const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
+          if (!(d2 < r2)) continue;
+          zanlungo_forward_force(rpx, rpy, d2, fc, fx, fy);
         }
       }
     }
@@ -637,8 +662,8 @@ __device__ __forceinline__ void zanlungo_velocity(const Own& o, const GroupDev& 
       fy = f_nan();
     }
   }
-  wx = o.u.x + fx * grp.inv_mass;  // recommended + force * (1/m), zanlungo.rs:216
-  wy = o.u.y + fy * grp.inv_mass;
+  wx = __builtin_fmaf(fx, grp.inv_mass, o.u.x);  // recommended + force * (1/m), zanlungo.rs:216
+  wy = __builtin_fmaf(fy, grp.inv_mass, o.u.y);
 }
 
 // get_bounds (location_hash_2d.rs:103-122) from a cell-relative position: cell range
@@ -745,23 +770,38 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
 }
 
 #define TILE_MAX_ROWS 17  // 2 * 8 + 1: eyesight up to 8 cells
+#define TILE_THREADS 256
 
 struct TileCfg {
-  int h;                 // ceil(max eyesight / cell)
-  uint32_t agents_cap;   // LDS slots for staged agents
-  uint32_t table_cap;    // u16 entries of the cell table
+  int h;                // ceil(max eyesight / cell)
+  uint32_t agents_cap;  // LDS slots for staged agents
+  uint32_t table_cap;   // u16 entries of the cell table
+  uint32_t list_cap;    // neighbour-list entries per thread
 };
 
-// K4 (tiled form): one workgroup = one BlockDesc.
-__global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in, EpilogueCtx E,
-                                                    const uint32_t* __restrict__ cell_start,
-                                                    const float2* __restrict__ pref,
-                                                    const BlockDesc* __restrict__ desc,
-                                                    const uint32_t* __restrict__ n_blocks, TileCfg cfg) {
+// Per-lane neighbour list entry: LDS slot of the neighbour (16 bits) and the cell it was
+// found in relative to the own cell, as two signed bytes.
+__device__ __forceinline__ uint32_t list_entry(uint32_t j, int dxc, int dyc) {
+  return j | ((uint32_t)(dxc & 0xFF) << 16) | ((uint32_t)(dyc & 0xFF) << 24);
+}
+
+// K4 (tiled form): one workgroup = one BlockDesc = up to 256 consecutive agents of one
+// grid row.  The (2h+1) cell-row segments around the strip are staged in LDS once (members
+// of a cell in ascending id), then every thread runs the neighbour pass of its agent:
+//   1. distance filter over the (2h+1)^2 cells around the agent -> compacted list in LDS
+//   2. time-to-collision over the list (min -> t_i); neighbours with right of way
+//      (larger id) are compacted to the front of the same list
+//   3. forces over that sub-list, in list (= canonical) order
+// Lists are bounded (list_cap); when any lane of a wave fills up, the wave processes what
+// it has and carries on (and pass 3 re-runs the filter, since the list was reused).
+__global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
+    StepParams P, AgentArrays in, EpilogueCtx E, const uint32_t* __restrict__ cell_start,
+    const float2* __restrict__ pref, const BlockDesc* __restrict__ desc,
+    const uint32_t* __restrict__ n_blocks, TileCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_g0[TILE_MAX_ROWS], s_base[TILE_MAX_ROWS + 1];
   {  // slots beyond the live population must not look alive to the next scatter
-    const uint32_t t = E.ctr->n_alive + blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = E.ctr->n_alive + blockIdx.x * TILE_THREADS + threadIdx.x;
     if (t < P.n) E.out.cell[t] = CS_INVALID_CELL;
   }
   if (blockIdx.x >= *n_blocks) return;
@@ -771,7 +811,8 @@ __global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in
   float2* s_off = reinterpret_cast<float2*>(smem);
   float2* s_vel = s_off + cfg.agents_cap;
   uint32_t* s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
-  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_id + cfg.agents_cap);
+  uint32_t* s_list = s_id + cfg.agents_cap;  // [list_cap][TILE_THREADS]
+  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
 
   // ---- geometry of the strip and its halo ----
   const int n_rows = (int)(g.ncells / g.nx);
@@ -804,13 +845,13 @@ __global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in
 
   if (tiled_ok) {
     // cell table: first LDS slot of every staged cell (+ one end marker per row)
-    for (int t = tid; t < nr * W1; t += 256) {
+    for (int t = tid; t < nr * W1; t += TILE_THREADS) {
       int k = t / W1, y = t - k * W1;
       unsigned long long rowbase = (unsigned long long)(r0 + k) * g.nx;
       s_tab[t] = (unsigned short)(s_base[k] + (cell_start[rowbase + sy0 + y] - s_g0[k]));
     }
     // agents, each placed at its cell's first slot + its rank by id inside the cell
-    for (uint32_t s = tid; s < S; s += 256) {
+    for (uint32_t s = tid; s < S; s += TILE_THREADS) {
       int k = 0;
       while (s >= s_base[k + 1]) ++k;
       const uint32_t j = s_g0[k] + (s - s_base[k]);
@@ -827,8 +868,9 @@ __global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in
   }
   __syncthreads();
 
-  if (tid >= (int)d.count) return;
-  const uint32_t i = d.first + tid;
+  // ---- one thread = one agent; idle lanes of the last wave keep the wave-uniform loops ----
+  const bool active = tid < (int)d.count;
+  const uint32_t i = d.first + (active ? tid : 0);
   const uint32_t cell = in.cell[i];
   Own o;
   o.gx = (uint32_t)R;
@@ -840,36 +882,177 @@ __global__ void __launch_bounds__(256) k_step_tiled(StepParams P, AgentArrays in
   const uint32_t meta = in.meta[i];
   const GroupDev grp = E.groups[meta & 0xFFFFu];
   o.u = hlp_velocity(grp, o.id, pref, i);
-  float wx = o.u.x, wy = o.u.y;
-  if (grp.lp_kind == 1u && o.off.x == o.off.x && o.off.y == o.off.y) {
-    bool tz;
-    // an agent whose offset left its cell (clamped below the grid, aliased above it)
-    // needs cells the strip did not stage
+  float wx = o.u.x, wy = o.u.y;  // NoLocalPlan: identity, no_local_plan.rs:9-17
+  const bool zan = active && grp.lp_kind == 1u && o.off.x == o.off.x && o.off.y == o.off.y;
+
+  // an agent whose offset left its cell (clamped below the grid, aliased above it), or whose
+  // reach crosses the row stride (where the reference aliases into the next row), needs
+  // cells the strip did not stage: exact gather path
+  int lx = 1, hx = 0, ly = 1, hy = 0;  // empty by default
+  bool use_tile = false;
+  if (zan) {
     const float slack = 0.01f * g.cs;
     const bool regular = o.off.x >= -slack && o.off.x <= g.cs + slack && o.off.y >= -slack &&
                          o.off.y <= g.cs + slack;
-    bool use_tile = tiled_ok && regular;
-    long long lx = 0, hx = 0, ly = 0, hy = 0;
-    if (use_tile) {
-      cell_bounds(o.off.x, grp.eyesight, g.inv_cs, o.gx, lx, hx);
-      cell_bounds(o.off.y, grp.eyesight, g.inv_cs, o.gy, ly, hy);
-      use_tile = hy < (long long)g.nx;  // beyond the stride the reference aliases into the next row
+    if (tiled_ok && regular) {
+      long long blx, bhx, bly, bhy;
+      cell_bounds(o.off.x, grp.eyesight, g.inv_cs, 0, blx, bhx);
+      cell_bounds(o.off.y, grp.eyesight, g.inv_cs, 0, bly, bhy);
+      use_tile = (long long)o.gy + bhy < (long long)g.nx;
       // f32 rounding at a cell edge can ask for one cell beyond ceil(r / cell); that cell
       // lies entirely out of reach
-      lx = max(lx, (long long)R - cfg.h);
-      hx = min(hx, (long long)R + cfg.h);
-      ly = max(ly, (long long)o.gy - cfg.h);
-      hy = min(hy, (long long)o.gy + cfg.h);
+      lx = (int)max(blx, (long long)-cfg.h);
+      hx = (int)min(bhx, (long long)cfg.h);
+      ly = (int)max(bly, (long long)-cfg.h);
+      hy = (int)min(bhy, (long long)cfg.h);
     }
-    if (use_tile) {
-      TiledSrc src{s_off, s_vel, s_id, s_tab, r0, r1, sy0, sy1, W1, o.id};
-      zanlungo_velocity(o, grp, g, lx, hx, ly, hy, src, wx, wy, tz);
-    } else {
-      gather_agent(P, in, cell_start, o, grp, wx, wy, tz);
-    }
+  }
+  if (zan && !use_tile) {
+    bool tz;
+    gather_agent(P, in, cell_start, o, grp, wx, wy, tz);
     if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
   }
-  step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
+
+  if (tiled_ok) {  // block-uniform; lanes without tile work run the loops with empty bounds
+    const bool mine = zan && use_tile;
+    if (!mine) {
+      lx = 1; hx = 0; ly = 1; hy = 0;
+    }
+    const float r2 = grp.eyesight * grp.eyesight;
+    const float R2 = grp.R * grp.R;
+    const int own_row = R - r0;
+    // own LDS slot, to skip self without touching ids
+    uint32_t self_slot = 0xFFFFFFFFu;
+    if (mine) {
+      const unsigned short* t = s_tab + own_row * W1 + ((int)o.gy - sy0);
+      for (uint32_t j = t[0]; j < t[1]; ++j)
+        if (s_id[j] == o.id) self_slot = j;
+    }
+    uint32_t* my_list = s_list + tid;
+    const uint32_t CAP = cfg.list_cap;
+    uint32_t cnt = 0, n_back = 0, n_fwd = 0;
+    float T = f_inf();
+    bool flushed = false;  // wave-uniform
+
+    // pass 2 over the first `n` entries of the list: t_i and the right-of-way sub-list
+    auto run_ttc = [&](uint32_t n) {
+      uint32_t w = 0;
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t ent = my_list[k * TILE_THREADS];
+        const uint32_t j = ent & 0xFFFFu;
+        const int dxc = (int)(ent << 8) >> 24, dyc = (int)ent >> 24;
+        const float oix = __builtin_fmaf(-(float)dxc, g.cs, o.off.x);
+        const float oiy = __builtin_fmaf(-(float)dyc, g.cs, o.off.y);
+        const float2 oj = s_off[j];
+        const float2 vj = s_vel[j];
+        const uint32_t idj = s_id[j];
+        const float rpx = oj.x - oix, rpy = oj.y - oiy;
+        const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
+        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, d2, R2);
+        T = (t < T) ? t : T;
+        if (idj > o.id) {
+          my_list[w * TILE_THREADS] = ent;  // w <= k: in place
+          ++w;
+        } else {
+          ++n_back;
+        }
+      }
+      n_fwd = w;
+    };
+    // pass 3 over the first `n` entries: forces of neighbours with right of way
+    float fx = 0.0f, fy = 0.0f;
+    ForceCtx fc;
+    auto run_force = [&](uint32_t n) {
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t ent = my_list[k * TILE_THREADS];
+        const uint32_t j = ent & 0xFFFFu;
+        const int dxc = (int)(ent << 8) >> 24, dyc = (int)ent >> 24;
+        const float oix = __builtin_fmaf(-(float)dxc, g.cs, o.off.x);
+        const float oiy = __builtin_fmaf(-(float)dyc, g.cs, o.off.y);
+        const float2 oj = s_off[j];
+        const float rpx = oj.x - oix, rpy = oj.y - oiy;
+        const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
+        zanlungo_forward_force(rpx, rpy, d2, fc, fx, fy);
+      }
+    };
+    // pass 1: the filter.  FORCE = false collects every neighbour in sight, FORCE = true only
+    // those with a larger id (used when the list had to be recycled).
+    auto sweep = [&](bool FORCE) {
+      for (int dx = -cfg.h; dx <= cfg.h; ++dx) {
+        const int rr = own_row + dx;  // staged row index, block-uniform
+        if (rr < 0 || rr >= nr) continue;
+        const bool x_in = dx >= lx && dx <= hx;
+        const float oix = __builtin_fmaf(-(float)dx, g.cs, o.off.x);
+        for (int dy = -cfg.h; dy <= cfg.h; ++dy) {
+          const int cy = (int)o.gy + dy - sy0;
+          uint32_t j = 0, e = 0;
+          if (x_in && dy >= ly && dy <= hy && cy >= 0 && cy < W1 - 1) {
+            const unsigned short* t = s_tab + rr * W1 + cy;
+            j = t[0];
+            e = t[1];
+          }
+          const float oiy = __builtin_fmaf(-(float)dy, g.cs, o.off.y);
+          while (__any(j < e)) {
+            while (j < e && cnt < CAP) {
+              const float2 oj = s_off[j];
+              const float rpx = oj.x - oix, rpy = oj.y - oiy;
+              const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
+              bool take = d2 < r2 && j != self_slot;  // strict `<`, location_hash_2d.rs:251
+              if (FORCE && take) take = s_id[j] > o.id;
+              if (take) {
+                my_list[cnt * TILE_THREADS] = list_entry(j, dx, dy);
+                ++cnt;
+              }
+              ++j;
+            }
+            if (__any(cnt >= CAP)) {  // some lane is full: everyone drains
+              if (FORCE) {
+                run_force(cnt);
+              } else {
+                run_ttc(cnt);
+                flushed = true;
+              }
+              cnt = 0;
+            }
+          }
+        }
+      }
+    };
+
+    sweep(false);
+    run_ttc(cnt);
+    const bool tz = (T == 0.0f);
+    if (mine && T != f_inf()) fc = make_force_ctx(o.v.x, o.v.y, T, grp);
+    else fc = ForceCtx{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // lanes with t_i = inf take no force (zanlungo.rs:211): give them an empty list
+    if (!__any(flushed)) {
+      run_force((T != f_inf()) ? n_fwd : 0u);
+    } else {
+      cnt = 0;
+      if (T == f_inf()) {
+        lx = 1; hx = 0;  // nothing to collect
+      }
+      sweep(true);
+      run_force(cnt);
+    }
+    if (mine) {
+      if (T != f_inf()) {
+        // Neighbours with a smaller id have weight 0: their term is (d/|d|) * 0 = 0, except
+        // with t_i == 0, where 0 * A * |dv| / 0 = NaN (zanlungo.rs:163; SURVEY.md KAT-Z3).
+        if (tz && n_back > 0) {
+          fx = f_nan();
+          fy = f_nan();
+        }
+      } else {
+        fx = 0.0f;
+        fy = 0.0f;
+      }
+      wx = __builtin_fmaf(fx, grp.inv_mass, o.u.x);  // recommended + force * (1/m), zanlungo.rs:216
+      wy = __builtin_fmaf(fy, grp.inv_mass, o.u.y);
+      if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
+    }
+  }
+  if (active) step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
 }
 
 // ---------------------------------------------------------------------------
@@ -1598,9 +1781,16 @@ struct cs_engine {
     if (tiled) {
       TileCfg cfg;
       cfg.h = h;
-      cfg.agents_cap = std::min<uint32_t>(7168u, ((uint32_t)(2 * h + 1) * 256u * 3u / 2u + 512u + 63u) & ~63u);
-      cfg.table_cap = 4096u;
-      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.table_cap * 2u;
+      // LDS budget: two workgroups per CU (<= 80 KiB each) while the tile allows it
+      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 5u / 4u + 256u + 63u) & ~63u);
+      cfg.table_cap = 2048u;
+      cfg.list_cap = 48u;
+      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * 4u +
+                   (size_t)cfg.table_cap * 2u;
+      while (lds > 80u * 1024u && cfg.list_cap > 16u) {
+        cfg.list_cap -= 8u;
+        lds -= 8u * TILE_THREADS * 4u;
+      }
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
                          blk_desc_cap, n_blocks_dev);
       uint32_t grid_blocks = (n_slots + 255u) / 256u + (uint32_t)std::min<uint64_t>(n_rows, n_slots);

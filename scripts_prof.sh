@@ -1,0 +1,31 @@
+#!/bin/bash
+# rocprofv3 passes over the bench workload; summaries land in gpurun_out/prof_<tag>/
+tag=${1:-r01}; shift
+args=${@:-"--steps 20 --warmup 5 --no-cpu-baseline"}
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py $args > $out/trace_bench.json 2> $out/trace.err || { echo trace failed; tail -5 $out/trace.err; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $out/pmc1 -o pmc1 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc1.err || { echo pmc1 failed; tail -5 $out/pmc1.err; }
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INST_LEVEL_LDS -d $out/pmc2 -o pmc2 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc2.err || { echo pmc2 failed; tail -5 $out/pmc2.err; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc3 -o pmc3 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc3.err || { echo pmc3 failed; tail -5 $out/pmc3.err; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc4 -o pmc4 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc4.err || { echo pmc4 failed; tail -5 $out/pmc4.err; }
+find $out -name "*.csv" | head -20
+python3 - <<PY
+import csv, glob, collections, os
+out="$out"
+for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read()[:3000])
+for tag in ("pmc1","pmc2","pmc3","pmc4"):
+    for f in glob.glob(out+f"/{tag}/**/*counter_collection.csv", recursive=True):
+        agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k=r["Kernel_Name"][:40]; agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
+            cnt[(k,r["Counter_Name"])]+=1
+        with open(out+f"/{tag}_summary.txt","w") as w:
+            for k,v in agg.items():
+                for c,val in v.items():
+                    line=f"{k:42s} {c:24s} per-launch {val/cnt[(k,c)]:.4g} launches {cnt[(k,c)]}"
+                    print(line); w.write(line+"\n")
+PY
