@@ -118,14 +118,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // (t0 = -inf, t1 = +inf -> 0).  Tiny relative velocities are therefore scaled by 2^48
 // first (t(s*rv) = t(rv)/s exactly); what still underflows takes the a -> 0 limit of
 // the same quadratic, which is what f64 computes there.  d2 = |rp|^2.
-__device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float d2,
-                                         float R2) {
-  float tscale = 1.0f;
-  if (fmaxf(fabsf(rvx), fabsf(rvy)) < 1e-12f) {
-    rvx *= 0x1p48f;
-    rvy *= 0x1p48f;
-    tscale = 0x1p48f;
-  }
+// Rare path: |rel_vel| < 1e-12 m/s.
+__device__ __noinline__ float ttc_tiny_f32(float rvx, float rvy, float rpx, float rpy, float d2,
+                                           float R2) {
+  const float tscale = 0x1p48f;
+  rvx *= tscale;
+  rvy *= tscale;
   const float a = __builtin_fmaf(rvx, rvx, rvy * rvy);
   const float bh = __builtin_fmaf(rvx, rpx, rvy * rpy);
   const float c = d2 - R2;
@@ -137,6 +135,23 @@ __device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float 
   const float disc = __builtin_fmaf(bh, bh, -(a * c));
   const float root = fast_sqrt(disc);
   const float ia = fast_rcp(a) * tscale;
+  const float t0 = (-bh - root) * ia;
+  const float t1 = (-bh + root) * ia;
+  float t = (t1 > 0.0f) ? ((t0 < 0.0f) ? 0.0f : t1) : f_inf();
+  t = (t0 > 0.0f) ? t0 : t;
+  return (disc < 0.0f) ? f_inf() : t;
+}
+
+__device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float d2,
+                                         float R2) {
+  if (__builtin_expect(fmaxf(fabsf(rvx), fabsf(rvy)) < 1e-12f, 0))
+    return ttc_tiny_f32(rvx, rvy, rpx, rpy, d2, R2);
+  const float a = __builtin_fmaf(rvx, rvx, rvy * rvy);  // >= 1e-24 here
+  const float bh = __builtin_fmaf(rvx, rpx, rvy * rpy);
+  const float c = d2 - R2;
+  const float disc = __builtin_fmaf(bh, bh, -(a * c));
+  const float root = fast_sqrt(disc);
+  const float ia = fast_rcp(a);
   const float t0 = (-bh - root) * ia;
   const float t1 = (-bh + root) * ia;
   float t = (t1 > 0.0f) ? ((t0 < 0.0f) ? 0.0f : t1) : f_inf();
@@ -415,6 +430,27 @@ __global__ void k_scatter(AgentArrays src, AgentArrays dst, uint32_t n,
   dst.meta[d] = src.meta[i];
 }
 
+// One returning atomic per distinct cell per wave instead of one per agent: the lanes that
+// share a cell elect a leader, which reserves popcount(lanes) slots; rank = base + lane order.
+__device__ __forceinline__ uint32_t wave_histogram_rank(uint32_t* __restrict__ cell_count,
+                                                        uint32_t cell, bool valid) {
+  const int lane = __lane_id();
+  uint32_t rank = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t c = __shfl(cell, leader, 64);
+    const bool same = valid && cell == c;
+    const unsigned long long m = __ballot(same);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cell_count[c], (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (same) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    todo &= ~m;
+  }
+  return rank;
+}
+
 // ---------------------------------------------------------------------------
 // Shared epilogue of the step kernels: integrate, re-bin, waypoint/sink test,
 // histogram for the next scatter, source-occupancy marks.
@@ -482,17 +518,21 @@ __device__ __forceinline__ void step_epilogue(const StepParams& P, const Epilogu
   if (destroyed) {
     uint32_t k = atomicAdd(&E.ctr->n_destroyed, 1u);
     if (k < E.destroyed_cap) E.destroyed[k] = make_uint2(id, meta);
-    E.out.cell[i] = CS_INVALID_CELL;
-    return;
+    ncell = CS_INVALID_CELL;
   }
-  E.out.off[i] = make_float2(nox, noy);
-  E.out.vel[i] = make_float2(wx, wy);
-  E.out.id[i] = id;
-  E.out.meta[i] = (meta & 0xFFFFu) | (next_wp << 16);
+  const bool keep = ncell != CS_INVALID_CELL;
+  if (keep) {
+    E.out.off[i] = make_float2(nox, noy);
+    E.out.vel[i] = make_float2(wx, wy);
+    E.out.id[i] = id;
+    E.out.meta[i] = (meta & 0xFFFFu) | (next_wp << 16);
+  }
   E.out.cell[i] = ncell;
-  if (ncell == CS_INVALID_CELL) return;
-  E.out.rank[i] = atomicAdd(&E.cell_count[ncell], 1u);
-
+  // histogram for the next scatter: agents are in cell order and few change cell per step,
+  // so the lanes of a wave hit a handful of counters; one atomic per distinct cell per wave
+  const uint32_t rank = wave_histogram_rank(E.cell_count, ncell, keep);
+  if (!keep) return;
+  E.out.rank[i] = rank;
   if (P.has_sinks) mark_sources(P.g, E.sinks, E.src_cell_start, E.src_sorted, E.src_occupied, ncell, nox, noy);
 }
 
@@ -777,27 +817,55 @@ struct TileCfg {
   uint32_t agents_cap;  // LDS slots for staged agents
   uint32_t table_cap;   // u16 entries of the cell table
   uint32_t list_cap;    // neighbour-list entries per thread
+  uint32_t debug;       // ablation switches for profiling (bench.py --debug), 0 in production
 };
 
-// Per-lane neighbour list entry: LDS slot of the neighbour (16 bits) and the cell it was
-// found in relative to the own cell, as two signed bytes.
-__device__ __forceinline__ uint32_t list_entry(uint32_t j, int dxc, int dyc) {
-  return j | ((uint32_t)(dxc & 0xFF) << 16) | ((uint32_t)(dyc & 0xFF) << 24);
-}
+// Per-lane neighbour list entry: LDS slot of the neighbour and the cell it was found in
+// relative to the own cell.  16-bit form (eyesight <= 1 cell, <= 4096 staged agents):
+// slot | (dy+1) << 12 | (dx+1) << 14.  32-bit form: slot | dx << 16 | dy << 24 (signed bytes).
+template <bool E16>
+struct ListEntry;
+template <>
+struct ListEntry<true> {
+  typedef unsigned short T;
+  static __device__ __forceinline__ T make(uint32_t j, int dx, int dy) {
+    return (T)(j | ((uint32_t)(dy + 1) << 12) | ((uint32_t)(dx + 1) << 14));
+  }
+  static __device__ __forceinline__ void unpack(T e, uint32_t& j, float& fdx, float& fdy) {
+    j = e & 0xFFFu;
+    fdx = (float)(int)((e >> 14) & 3u) - 1.0f;
+    fdy = (float)(int)((e >> 12) & 3u) - 1.0f;
+  }
+};
+template <>
+struct ListEntry<false> {
+  typedef uint32_t T;
+  static __device__ __forceinline__ T make(uint32_t j, int dx, int dy) {
+    return j | ((uint32_t)(dx & 0xFF) << 16) | ((uint32_t)(dy & 0xFF) << 24);
+  }
+  static __device__ __forceinline__ void unpack(T e, uint32_t& j, float& fdx, float& fdy) {
+    j = e & 0xFFFFu;
+    fdx = (float)((int)(e << 8) >> 24);
+    fdy = (float)((int)e >> 24);
+  }
+};
 
 // K4 (tiled form): one workgroup = one BlockDesc = up to 256 consecutive agents of one
 // grid row.  The (2h+1) cell-row segments around the strip are staged in LDS once (members
 // of a cell in ascending id), then every thread runs the neighbour pass of its agent:
 //   1. distance filter over the (2h+1)^2 cells around the agent -> compacted list in LDS
-//   2. time-to-collision over the list (min -> t_i); neighbours with right of way
-//      (larger id) are compacted to the front of the same list
-//   3. forces over that sub-list, in list (= canonical) order
-// Lists are bounded (list_cap); when any lane of a wave fills up, the wave processes what
-// it has and carries on (and pass 3 re-runs the filter, since the list was reused).
+//   2. time-to-collision over the list (min -> t_i); the neighbours with right of way
+//      (larger id) are remembered in a 64-bit lane mask
+//   3. forces over the marked entries, in list (= canonical) order
+// Lists are bounded (list_cap <= 64); when any lane of a wave fills up, the wave processes
+// what it has and carries on (pass 3 then re-runs the filter, since the list was recycled).
+template <bool E16>
 __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     StepParams P, AgentArrays in, EpilogueCtx E, const uint32_t* __restrict__ cell_start,
     const float2* __restrict__ pref, const BlockDesc* __restrict__ desc,
     const uint32_t* __restrict__ n_blocks, TileCfg cfg) {
+  typedef ListEntry<E16> LE;
+  typedef typename LE::T entry_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_g0[TILE_MAX_ROWS], s_base[TILE_MAX_ROWS + 1];
   {  // slots beyond the live population must not look alive to the next scatter
@@ -808,11 +876,12 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   const BlockDesc d = desc[blockIdx.x];
   const GridDev g = P.g;
   const int tid = threadIdx.x;
-  float2* s_off = reinterpret_cast<float2*>(smem);
-  float2* s_vel = s_off + cfg.agents_cap;
-  uint32_t* s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
-  uint32_t* s_list = s_id + cfg.agents_cap;  // [list_cap][TILE_THREADS]
-  unsigned short* s_tab = reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
+  float2* __restrict__ s_off = reinterpret_cast<float2*>(smem);
+  float2* __restrict__ s_vel = s_off + cfg.agents_cap;
+  uint32_t* __restrict__ s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
+  entry_t* __restrict__ s_list = reinterpret_cast<entry_t*>(s_id + cfg.agents_cap);  // [cap][256]
+  unsigned short* __restrict__ s_tab =
+      reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
 
   // ---- geometry of the strip and its halo ----
   const int n_rows = (int)(g.ncells / g.nx);
@@ -841,14 +910,15 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   }
   __syncthreads();
   const uint32_t S = s_base[nr];
-  const bool tiled_ok = S <= cfg.agents_cap && S < 65535u && (uint32_t)(nr * W1) <= cfg.table_cap;
+  const bool tiled_ok = S <= cfg.agents_cap && S < (E16 ? 4096u : 65535u) &&
+                        (uint32_t)(nr * W1) <= cfg.table_cap;
 
   if (tiled_ok) {
     // cell table: first LDS slot of every staged cell (+ one end marker per row)
-    for (int t = tid; t < nr * W1; t += TILE_THREADS) {
-      int k = t / W1, y = t - k * W1;
-      unsigned long long rowbase = (unsigned long long)(r0 + k) * g.nx;
-      s_tab[t] = (unsigned short)(s_base[k] + (cell_start[rowbase + sy0 + y] - s_g0[k]));
+    for (int k = 0; k < nr; ++k) {
+      const unsigned long long rowbase = (unsigned long long)(r0 + k) * g.nx + sy0;
+      for (int y = tid; y < W1; y += TILE_THREADS)
+        s_tab[k * W1 + y] = (unsigned short)(s_base[k] + (cell_start[rowbase + y] - s_g0[k]));
     }
     // agents, each placed at its cell's first slot + its rank by id inside the cell
     for (uint32_t s = tid; s < S; s += TILE_THREADS) {
@@ -859,7 +929,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       const uint32_t idj = in.id[j];
       const uint32_t cb = cell_start[cj], ce = cell_start[cj + 1];
       uint32_t rank = 0;
-      for (uint32_t q = cb; q < ce; ++q) rank += (in.id[q] < idj) ? 1u : 0u;
+      if (cfg.debug & 2u) rank = j - cb;
+      else
+        for (uint32_t q = cb; q < ce; ++q) rank += (in.id[q] < idj) ? 1u : 0u;
       const uint32_t slot = s_base[k] + (cb - s_g0[k]) + rank;
       s_off[slot] = in.off[j];
       s_vel[slot] = in.vel[j];
@@ -913,7 +985,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
   }
 
-  if (tiled_ok) {  // block-uniform; lanes without tile work run the loops with empty bounds
+  if (tiled_ok && !(cfg.debug & 1u)) {  // block-uniform; lanes without tile work idle through
     const bool mine = zan && use_tile;
     if (!mine) {
       lx = 1; hx = 0; ly = 1; hy = 0;
@@ -928,49 +1000,51 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       for (uint32_t j = t[0]; j < t[1]; ++j)
         if (s_id[j] == o.id) self_slot = j;
     }
-    uint32_t* my_list = s_list + tid;
+    entry_t* __restrict__ my_list = s_list + tid;
     const uint32_t CAP = cfg.list_cap;
-    uint32_t cnt = 0, n_back = 0, n_fwd = 0;
+    uint32_t cnt = 0, n_back = 0;
+    unsigned long long fwd = 0;  // bit k: list entry k has right of way over this agent
     float T = f_inf();
     bool flushed = false;  // wave-uniform
 
-    // pass 2 over the first `n` entries of the list: t_i and the right-of-way sub-list
+    auto rel = [&](entry_t ent, uint32_t& j, float& rpx, float& rpy) {
+      float fdx, fdy;
+      LE::unpack(ent, j, fdx, fdy);
+      // own offset as seen from the neighbour's cell: p_j - p_i = off_j - (off_i - shift)
+      const float oix = __builtin_fmaf(-fdx, g.cs, o.off.x);
+      const float oiy = __builtin_fmaf(-fdy, g.cs, o.off.y);
+      const float2 oj = s_off[j];
+      rpx = oj.x - oix;
+      rpy = oj.y - oiy;
+    };
+    // pass 2 over the first `n` entries of the list: t_i and the right-of-way mask
     auto run_ttc = [&](uint32_t n) {
-      uint32_t w = 0;
+      unsigned long long m = 0;
       for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t ent = my_list[k * TILE_THREADS];
-        const uint32_t j = ent & 0xFFFFu;
-        const int dxc = (int)(ent << 8) >> 24, dyc = (int)ent >> 24;
-        const float oix = __builtin_fmaf(-(float)dxc, g.cs, o.off.x);
-        const float oiy = __builtin_fmaf(-(float)dyc, g.cs, o.off.y);
-        const float2 oj = s_off[j];
+        uint32_t j;
+        float rpx, rpy;
+        rel(my_list[k * TILE_THREADS], j, rpx, rpy);
         const float2 vj = s_vel[j];
         const uint32_t idj = s_id[j];
-        const float rpx = oj.x - oix, rpy = oj.y - oiy;
         const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
         const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, d2, R2);
         T = (t < T) ? t : T;
-        if (idj > o.id) {
-          my_list[w * TILE_THREADS] = ent;  // w <= k: in place
-          ++w;
-        } else {
-          ++n_back;
-        }
+        const bool f = idj > o.id;
+        m |= f ? (1ull << k) : 0ull;
+        n_back += f ? 0u : 1u;
       }
-      n_fwd = w;
+      fwd = m;
     };
-    // pass 3 over the first `n` entries: forces of neighbours with right of way
+    // pass 3: forces of the listed neighbours selected by `mask`, in list order
     float fx = 0.0f, fy = 0.0f;
     ForceCtx fc;
-    auto run_force = [&](uint32_t n) {
-      for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t ent = my_list[k * TILE_THREADS];
-        const uint32_t j = ent & 0xFFFFu;
-        const int dxc = (int)(ent << 8) >> 24, dyc = (int)ent >> 24;
-        const float oix = __builtin_fmaf(-(float)dxc, g.cs, o.off.x);
-        const float oiy = __builtin_fmaf(-(float)dyc, g.cs, o.off.y);
-        const float2 oj = s_off[j];
-        const float rpx = oj.x - oix, rpy = oj.y - oiy;
+    auto run_force = [&](unsigned long long mask) {
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        uint32_t j;
+        float rpx, rpy;
+        rel(my_list[k * TILE_THREADS], j, rpx, rpy);
         const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
         zanlungo_forward_force(rpx, rpy, d2, fc, fx, fy);
       }
@@ -1000,14 +1074,14 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
               bool take = d2 < r2 && j != self_slot;  // strict `<`, location_hash_2d.rs:251
               if (FORCE && take) take = s_id[j] > o.id;
               if (take) {
-                my_list[cnt * TILE_THREADS] = list_entry(j, dx, dy);
+                my_list[cnt * TILE_THREADS] = LE::make(j, dx, dy);
                 ++cnt;
               }
               ++j;
             }
             if (__any(cnt >= CAP)) {  // some lane is full: everyone drains
               if (FORCE) {
-                run_force(cnt);
+                run_force(cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull));
               } else {
                 run_ttc(cnt);
                 flushed = true;
@@ -1024,16 +1098,16 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     const bool tz = (T == 0.0f);
     if (mine && T != f_inf()) fc = make_force_ctx(o.v.x, o.v.y, T, grp);
     else fc = ForceCtx{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // lanes with t_i = inf take no force (zanlungo.rs:211): give them an empty list
+    // lanes with t_i = inf take no force (zanlungo.rs:211)
     if (!__any(flushed)) {
-      run_force((T != f_inf()) ? n_fwd : 0u);
+      run_force((T != f_inf()) ? fwd : 0ull);
     } else {
       cnt = 0;
       if (T == f_inf()) {
         lx = 1; hx = 0;  // nothing to collect
       }
       sweep(true);
-      run_force(cnt);
+      run_force(cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull));
     }
     if (mine) {
       if (T != f_inf()) {
@@ -1052,7 +1126,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       if (tz) atomicAdd(&E.ctr->n_tti_zero, 1u);
     }
   }
-  if (active) step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
+  if (active && !(cfg.debug & 4u)) step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
 }
 
 // ---------------------------------------------------------------------------
@@ -1253,6 +1327,8 @@ struct cs_engine {
   uint32_t blk_desc_cap = 0;
   uint32_t* n_blocks_dev = nullptr;
   double max_eyesight = 0.0;
+  uint32_t tile_blocks_per_cu = 3;  // LDS budget target of the tiled kernel (tuning knobs)
+  uint32_t tile_list_cap = 0;       // 0 = derive from the budget
 
   // planners as data
   std::vector<cs_zanlungo_params> lp_params;
@@ -1781,24 +1857,39 @@ struct cs_engine {
     if (tiled) {
       TileCfg cfg;
       cfg.h = h;
-      // LDS budget: two workgroups per CU (<= 80 KiB each) while the tile allows it
-      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 5u / 4u + 256u + 63u) & ~63u);
-      cfg.table_cap = 2048u;
-      cfg.list_cap = 48u;
-      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * 4u +
-                   (size_t)cfg.table_cap * 2u;
-      while (lds > 80u * 1024u && cfg.list_cap > 16u) {
-        cfg.list_cap -= 8u;
-        lds -= 8u * TILE_THREADS * 4u;
+      cfg.debug = (flags >> 8) & 0xFFu;
+      // LDS budget per workgroup: staged agents (20 B each, ~(2h+1) strips of 256 + halo ends),
+      // the cell table and the per-thread neighbour lists; sized so that `tile_blocks_per_cu`
+      // workgroups fit in the 160 KiB of a CU
+      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 9u / 8u + 192u + 63u) & ~63u);
+      cfg.table_cap = 1024u * (uint32_t)(h > 1 ? 2 : 1);
+      const bool e16 = h <= 1 && cfg.agents_cap <= 4096u;
+      const size_t entry = e16 ? 2u : 4u;
+      const size_t fixed = (size_t)cfg.agents_cap * 20u + (size_t)cfg.table_cap * 2u + 256u;
+      const size_t budget = (size_t)(160u * 1024u) / std::max(1u, tile_blocks_per_cu);
+      cfg.list_cap = tile_list_cap;
+      if (!cfg.list_cap) {
+        cfg.list_cap = 16u;
+        while (cfg.list_cap + 8u <= 64u && fixed + (size_t)(cfg.list_cap + 8u) * TILE_THREADS * entry <= budget)
+          cfg.list_cap += 8u;
       }
+      cfg.list_cap = std::min(cfg.list_cap, 64u);
+      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * entry +
+                   (size_t)cfg.table_cap * 2u;
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
                          blk_desc_cap, n_blocks_dev);
       uint32_t grid_blocks = (n_slots + 255u) / 256u + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
       grid_blocks = std::min(grid_blocks, blk_desc_cap);
       prof_begin(CS_K_NEIGHBOUR_FORCE);
       if (n_slots)
-        hipLaunchKernelGGL(k_step_tiled, dim3(grid_blocks), dim3(256), lds, stream, P, buf[cur], E,
-                           cell_start, pref, blk_desc, n_blocks_dev, cfg);
+      {
+        if (e16)
+          hipLaunchKernelGGL(k_step_tiled<true>, dim3(grid_blocks), dim3(TILE_THREADS), lds, stream, P,
+                             buf[cur], E, cell_start, pref, blk_desc, n_blocks_dev, cfg);
+        else
+          hipLaunchKernelGGL(k_step_tiled<false>, dim3(grid_blocks), dim3(TILE_THREADS), lds, stream, P,
+                             buf[cur], E, cell_start, pref, blk_desc, n_blocks_dev, cfg);
+      }
       prof_end();
     } else {
       prof_begin(CS_K_NEIGHBOUR_FORCE);
@@ -1984,9 +2075,11 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, e->device);
   e->backend = std::string("hip:") + prop.gcnArchName;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled),
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
     (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
+  if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
   bool ok = true;
   ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;

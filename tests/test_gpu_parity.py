@@ -127,6 +127,26 @@ def test_kat_z3_overlap_nan_semantics():
     assert len(sim) == 2 and math.isnan(sim.agents[1].position[1])
 
 
+@pytest.mark.parametrize("speed", [1e-20, 1e-35])
+def test_tiny_relative_velocities_do_not_read_as_collisions(speed):
+    """|rel_vel|^2 underflows in f32 (not in the reference's f64): a flushed `a` with b != 0
+    would make t0 = -inf, t1 = +inf read as "colliding now".  The kernel rescales / takes the
+    a -> 0 limit instead (ttc_tiny_f32); both sides must see a huge finite t_i, not 0."""
+    out = []
+    for cls in (Simulation, OracleSimulation):
+        sim = cls(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        sim.add_agents([(50.0, 50.0)], StubHighLevelPlan((speed, 0.0)), lp, 2.0)
+        sim.add_agents([(51.0, 50.05)], StubHighLevelPlan((0.0, 0.0)), lp, 2.0)
+        sim.step(0.05)
+        sim.step(0.05)
+        assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0
+        out.append(sim.read_agents())
+    a, b = out
+    assert np.allclose(a["vx"], b["vx"], rtol=1e-5, atol=0.0) and np.allclose(a["vy"], b["vy"], atol=1e-30)
+    assert np.allclose(a["x"], b["x"], atol=1e-6)
+
+
 # ---- config 1: the visualiser's scene ---------------------------------------------------
 def test_viz_scene_literal_1000_steps():
     """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),
