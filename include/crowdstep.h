@@ -48,14 +48,18 @@ typedef struct cs_grid_desc {
   double offset_y;
 } cs_grid_desc;
 
-/* Device placement.  A tile engine owns the cell columns/rows
- * [tile_cx0, tile_cx1) x [tile_cy0, tile_cy1) of the global grid and keeps a
- * ghost ring for neighbour queries (multi-GPU, DESIGN.md "Tiles").
+/* Device placement.  A tile engine owns the cells [tile_cx0, tile_cx1) x
+ * [tile_cy0, tile_cy1) of the global grid (x = the index location_to_index
+ * multiplies by the row stride, location_hash_2d.rs:59) and keeps a ghost ring
+ * of halo_cells cells for neighbour queries (multi-GPU, DESIGN.md "Tiles");
+ * halo_cells must be >= ceil(max eyesight / cell_size).
  * All-zero tile bounds = the engine owns the whole grid. */
 typedef struct cs_device_cfg {
   int32_t device_ordinal;   /* HIP device index for this engine               */
   uint32_t flags;           /* CS_CFG_* bits                                  */
   uint32_t tile_cx0, tile_cx1, tile_cy0, tile_cy1;
+  uint32_t halo_cells;
+  uint32_t reserved;
   uint64_t capacity_hint;   /* expected max agents (0 = grow on demand)       */
   void* stream;             /* hipStream_t to run on (NULL = engine's own)    */
 } cs_device_cfg;
@@ -233,16 +237,24 @@ int cs_profile_read(cs_engine*, uint32_t kernel, double* total_ms, uint64_t* lau
 void cs_profile_reset(cs_engine*);
 
 /* ---- tiles: halo exchange hooks (multi-GPU, one engine per rank) -------- */
-/* Directions of the two-phase exchange: X first, then Y (corners forward). */
+/* The reference has no counterpart (single process).  Per step and tile:
+ *   cs_halo_pack(0) -> move XLO/XHI send buffers to the neighbours' recv buffers
+ *   -> cs_halo_unpack(0) -> cs_halo_pack(1) -> move YLO/YHI -> cs_halo_unpack(1)
+ *   -> cs_step.   The transport is the caller's (RCCL send/recv, torch.distributed,
+ * hipMemcpyPeer): the engine only fills and drains device buffers, on its stream.
+ * In tile mode cs_add_agents takes the GLOBAL position list on every tile (ids are
+ * allocated for all of it, agents outside the owned cells are skipped). */
 enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3 };
 #define CS_HALO_RECORD_BYTES 32u
-/* Caller-provided device buffers (e.g. torch CUDA tensors): capacity in records.
- * Word 0 of each buffer is the record count header. */
+/* Caller-provided device buffers (e.g. torch CUDA tensors) of
+ * (capacity_records + 1) * CS_HALO_RECORD_BYTES bytes: record 0 is the header
+ * (word 0 = record count).  A direction without a neighbour tile gets no buffers. */
 int cs_halo_set_buffers(cs_engine*, uint32_t dir, void* send_dev, void* recv_dev,
                         uint64_t capacity_records);
-/* Pack border + migrating agents for one axis (0 = X pair, 1 = Y pair). */
+/* Fill the two send buffers of one axis (0 = X pair, 1 = Y pair) with every agent
+ * within 2 * halo_cells of the shared edge. */
 int cs_halo_pack(cs_engine*, uint32_t axis);
-/* Merge what arrived on one axis into the unsorted tail of the tile. */
+/* Merge what arrived on one axis into the tile (as owned agents or ghosts, by cell). */
 int cs_halo_unpack(cs_engine*, uint32_t axis);
 
 #ifdef __cplusplus

@@ -30,6 +30,7 @@ class DeviceCfg(C.Structure):
     _fields_ = [("device_ordinal", C.c_int32), ("flags", C.c_uint32),
                 ("tile_cx0", C.c_uint32), ("tile_cx1", C.c_uint32),
                 ("tile_cy0", C.c_uint32), ("tile_cy1", C.c_uint32),
+                ("halo_cells", C.c_uint32), ("reserved", C.c_uint32),
                 ("capacity_hint", C.c_uint64), ("stream", C.c_void_p)]
 
 

@@ -68,5 +68,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). rmf_crowdsim_amd has no CPU fallback.")
+    # One process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 (same
+    # SONAME as /opt/rocm's); whichever loads first serves both.  torch only works on its own
+    # copy, so when torch is installed it goes first (bench.py and the tile transports use torch
+    # streams / torch.distributed next to the engine).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     _lib = _abi.bind(ctypes.CDLL(LIB_PATH))
     return _lib

@@ -41,6 +41,13 @@ struct GridDev {
   float cs;         // cell size, f32
   float cs_lo;      // cell_size - (double)cs, second word for exact re-basing
   float inv_cs;
+  // tile mode (one engine per GPU): the local grid is the owned cell rectangle
+  // [own_x0, own_x1) x [own_y0, own_y1) (local cell coordinates) plus its ghost ring; local
+  // cell (0,0) is global cell (org_x, org_y).  Not a tile: tile = 0 and the owned rectangle
+  // is the whole grid.
+  uint32_t tile;
+  uint32_t own_x0, own_x1, own_y0, own_y1;
+  uint32_t org_x, org_y;
 };
 
 // One group per add_agents call / per source-sink: the reference passes the
@@ -69,6 +76,8 @@ struct Counters {
   // persistent
   uint32_t n_alive;          // written by the scan: total of the histogram
   uint32_t n_out_of_bounds;  // cumulative: any non-zero value poisons the engine
+  uint32_t n_owned;          // agents in the owned rectangle (tile mode; else = n_alive)
+  uint32_t n_pending;        // slots in use in the unsorted buffer (halo unpack appends)
   // per step (zeroed before each step)
   uint32_t n_destroyed;
   uint32_t n_waypoint_hits;
@@ -77,9 +86,10 @@ struct Counters {
   uint32_t n_clamped;
   uint32_t n_spawned;
   uint32_t n_wp_events;
-  uint32_t pad[7];
+  uint32_t n_halo_overflow;
+  uint32_t pad[4];
 };
-#define CS_COUNTERS_PER_STEP_OFFSET (2 * sizeof(uint32_t))
+#define CS_COUNTERS_PER_STEP_OFFSET (4 * sizeof(uint32_t))
 
 struct AgentArrays {
   float2* off;
@@ -235,7 +245,10 @@ __device__ __forceinline__ uint32_t rebin(const GridDev& g, uint32_t gx, uint32_
   }
   if (clamped) atomicAdd(&ctr->n_clamped, 1u);
   unsigned long long flat = (unsigned long long)cx * g.nx + (unsigned long long)cy;
-  if (flat >= g.ncells) {
+  // a tile has real neighbours instead of the reference's clamp / alias behaviour at its
+  // edges: anything that leaves the local rectangle (more than a ghost ring in one step,
+  // or out of the global grid) is an error
+  if (flat >= g.ncells || (g.tile && (clamped || cy >= (long long)g.nx))) {
     atomicAdd(&ctr->n_out_of_bounds, 1u);
     return CS_INVALID_CELL;
   }
@@ -287,9 +300,10 @@ __device__ __forceinline__ void mark_sources(const GridDev& g, const SinkDev* __
 // ---------------------------------------------------------------------------
 // K1: histogram + arrival rank (used when the histogram kept by k_step is stale)
 // ---------------------------------------------------------------------------
-__global__ void k_count(AgentArrays a, uint32_t first, uint32_t n, uint32_t* __restrict__ cell_count) {
+__global__ void k_count(AgentArrays a, uint32_t first, uint32_t n, uint32_t* __restrict__ cell_count,
+                        const Counters* __restrict__ ctr, uint32_t tile) {
   uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (tile && i >= ctr->n_pending)) return;
   uint32_t c = a.cell[i];
   if (c == CS_INVALID_CELL) return;
   a.rank[i] = atomicAdd(&cell_count[c], 1u);
@@ -410,6 +424,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
     }
     cell_start[ncells] = total;
     ctr->n_alive = total;
+    ctr->n_owned = total;
   }
 }
 
@@ -417,9 +432,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
 // K3: scatter records into cell order
 // ---------------------------------------------------------------------------
 __global__ void k_scatter(AgentArrays src, AgentArrays dst, uint32_t n,
-                          const uint32_t* __restrict__ cell_start) {
+                          const uint32_t* __restrict__ cell_start, const Counters* __restrict__ ctr,
+                          uint32_t tile) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (tile && i >= ctr->n_pending)) return;
   uint32_t c = src.cell[i];
   if (c == CS_INVALID_CELL) return;
   uint32_t d = cell_start[c] + src.rank[i];
@@ -745,6 +761,10 @@ __global__ void __launch_bounds__(256) k_step_gather(StepParams P, AgentArrays i
   Own o;
   o.gx = cell / P.g.nx;
   o.gy = cell - o.gx * P.g.nx;
+  if (P.g.tile && (o.gx < P.g.own_x0 || o.gx >= P.g.own_x1 || o.gy < P.g.own_y0 || o.gy >= P.g.own_y1)) {
+    E.out.cell[i] = CS_INVALID_CELL;  // a ghost: its owner steps it
+    return;
+  }
   o.off = in.off[i];
   o.v = in.vel[i];
   o.id = in.id[i];
@@ -772,23 +792,29 @@ struct BlockDesc {
 
 __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t* __restrict__ cell_start,
                                                        BlockDesc* __restrict__ desc, uint32_t desc_cap,
-                                                       uint32_t* __restrict__ n_blocks) {
+                                                       uint32_t* __restrict__ n_blocks,
+                                                       Counters* __restrict__ ctr) {
   __shared__ uint32_t wsum[16];
-  __shared__ uint32_t s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
+  __shared__ uint32_t s_carry, s_owned;
+  if (threadIdx.x == 0) {
+    s_carry = 0;
+    s_owned = 0;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n_rows = g.ncells / g.nx;
+  // only the owned rows / columns get workgroups; ghosts are read, never stepped
+  const uint32_t n_rows = g.own_x1 - g.own_x0;
   for (uint32_t base = 0; base < n_rows; base += blockDim.x) {
-    uint32_t R = base + threadIdx.x;
+    uint32_t R = g.own_x0 + base + threadIdx.x;
     uint32_t first = 0, cnt = 0;
-    if (R < n_rows) {
-      first = cell_start[(unsigned long long)R * g.nx];
-      cnt = cell_start[(unsigned long long)(R + 1) * g.nx] - first;
+    if (R < g.own_x1) {
+      first = cell_start[(unsigned long long)R * g.nx + g.own_y0];
+      cnt = cell_start[(unsigned long long)R * g.nx + g.own_y1] - first;
     }
     uint32_t nb = (cnt + 255u) / 256u;
     uint32_t incl = wave_incl_scan(nb, lane);
     if (lane == 63) wsum[wave] = incl;
+    if (cnt) atomicAdd(&s_owned, cnt);
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
@@ -806,7 +832,12 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
     if (threadIdx.x == blockDim.x - 1) s_carry = excl + nb;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_blocks = min(s_carry, desc_cap);
+  if (threadIdx.x == 0) {
+    *n_blocks = min(s_carry, desc_cap);
+    ctr->n_owned = s_owned;
+    // runs after the scatter, before the step kernel, which writes one slot per sorted agent
+    ctr->n_pending = cell_start[g.ncells];
+  }
 }
 
 #define TILE_MAX_ROWS 17  // 2 * 8 + 1: eyesight up to 8 cells
@@ -1130,6 +1161,74 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
 }
 
 // ---------------------------------------------------------------------------
+// K7: halo exchange of a tile (DESIGN.md "Tiles").  A record is what a neighbour tile needs
+// to see an agent: cell-relative state + its GLOBAL cell.  Ownership is decided by cell
+// alone, so migrants and ghosts travel the same way: everything within 2*halo cells of a
+// shared edge (the ghost ring itself holds the agents that just walked out) is sent.
+// Buffer layout: record 0 is the header (word 0 = record count), records follow.
+// ---------------------------------------------------------------------------
+struct HaloRecord {
+  float ox, oy, vx, vy;
+  uint32_t id, meta, gcx, gcy;
+};
+static_assert(sizeof(HaloRecord) == CS_HALO_RECORD_BYTES, "halo record layout");
+
+__device__ __forceinline__ void halo_append(HaloRecord* __restrict__ buf, uint32_t cap, const HaloRecord& r,
+                                            Counters* ctr) {
+  uint32_t k = atomicAdd(reinterpret_cast<uint32_t*>(buf), 1u);
+  if (k < cap) buf[k + 1] = r;
+  else atomicAdd(&ctr->n_halo_overflow, 1u);
+}
+
+__global__ void k_halo_pack(GridDev g, AgentArrays a, uint32_t n_ub, uint32_t axis, uint32_t band,
+                            HaloRecord* __restrict__ send_lo, HaloRecord* __restrict__ send_hi,
+                            uint32_t cap, Counters* __restrict__ ctr) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ub || i >= ctr->n_pending) return;
+  const uint32_t c = a.cell[i];
+  if (c == CS_INVALID_CELL) return;
+  const uint32_t cx = c / g.nx, cy = c - cx * g.nx;
+  const uint32_t q = axis == 0 ? cx : cy;
+  const uint32_t extent = axis == 0 ? g.ncells / g.nx : g.nx;
+  const bool lo = send_lo != nullptr && q < band;
+  const bool hi = send_hi != nullptr && q + band >= extent;
+  if (!lo && !hi) return;
+  HaloRecord r;
+  const float2 o = a.off[i], v = a.vel[i];
+  r.ox = o.x; r.oy = o.y; r.vx = v.x; r.vy = v.y;
+  r.id = a.id[i];
+  r.meta = a.meta[i];
+  r.gcx = g.org_x + cx;
+  r.gcy = g.org_y + cy;
+  if (lo) halo_append(send_lo, cap, r, ctr);
+  if (hi) halo_append(send_hi, cap, r, ctr);
+}
+
+__global__ void k_halo_unpack(GridDev g, AgentArrays a, uint32_t slot_cap,
+                              const HaloRecord* __restrict__ recv, uint32_t cap,
+                              uint32_t* __restrict__ cell_count, Counters* __restrict__ ctr) {
+  const uint32_t n = min(reinterpret_cast<const uint32_t*>(recv)[0], cap);
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const HaloRecord r = recv[i + 1];
+  const long long lx = (long long)r.gcx - (long long)g.org_x, ly = (long long)r.gcy - (long long)g.org_y;
+  const long long n_rows = g.ncells / g.nx;
+  if (lx < 0 || ly < 0 || lx >= n_rows || ly >= (long long)g.nx) return;  // not in my ring
+  const uint32_t slot = atomicAdd(&ctr->n_pending, 1u);
+  if (slot >= slot_cap) {
+    atomicAdd(&ctr->n_halo_overflow, 1u);
+    return;
+  }
+  const uint32_t cell = (uint32_t)lx * g.nx + (uint32_t)ly;
+  a.off[slot] = make_float2(r.ox, r.oy);
+  a.vel[slot] = make_float2(r.vx, r.vy);
+  a.id[slot] = r.id;
+  a.meta[slot] = r.meta;
+  a.cell[slot] = cell;
+  a.rank[slot] = atomicAdd(&cell_count[cell], 1u);
+}
+
+// ---------------------------------------------------------------------------
 // K6: spawn.  One block; sinks in ascending handle order.  A sink spawns ONE
 // agent at its source iff its generator asked for > 0 and nobody stood within
 // 0.4 of the source at the end of the previous step (lib.rs:199-254).
@@ -1294,8 +1393,16 @@ struct HostGroup {
 struct cs_engine {
   // grid (LocationHash2D::new, location_hash_2d.rs:33-51)
   cs_grid_desc grid;
-  uint64_t nx = 0, ny = 0, ncells = 0;
+  uint64_t nx = 0, ny = 0, ncells = 0;  // LOCAL grid: nx = row stride (columns), ny = rows
+  uint64_t gnx = 0, gny = 0;            // global grid (== local unless this is a tile)
   GridDev gdev;
+  bool tile = false;
+  uint32_t halo_cells = 0;
+  struct HaloDir {
+    HaloRecord* send = nullptr;
+    HaloRecord* recv = nullptr;
+    uint32_t cap = 0;
+  } halo[4];
   int device = 0;
   uint32_t flags = 0;
   hipStream_t stream = nullptr;
@@ -1382,6 +1489,7 @@ struct cs_engine {
     a = AgentArrays{};
   }
   int reserve(uint64_t need) {
+    for (int d = 0; d < 4; ++d) need += 2ull * halo[d].cap;  // last step's ghosts + this step's arrivals
     if (need <= cap) return 0;
     uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(1024, cap * 2));
     if (ncap >= 0xFFFFFFF0ull) {
@@ -1464,20 +1572,33 @@ struct cs_engine {
   // ---- conversions ----
   // location_to_index (location_hash_2d.rs:54-66) in f64, then the offset from
   // the stored cell's geometric origin, rounded once to f32.
-  bool to_cell(double x, double y, uint32_t* cell, float* ox, float* oy) const {
+  // returns 0 = ok, 1 = "Index out of bounds", 2 = valid but not in this tile's owned cells
+  int to_cell(double x, double y, uint32_t* cell, float* ox, float* oy) const {
     uint64_t xi = sat_usize((x - grid.offset_x) / grid.cell_size);
     uint64_t yi = sat_usize((y - grid.offset_y) / grid.cell_size);
-    unsigned __int128 idx = (unsigned __int128)xi * nx + yi;
-    if (idx >= ncells) return false;
-    uint64_t flat = (uint64_t)idx;
-    uint64_t sx = flat / nx, sy = flat % nx;
-    *cell = (uint32_t)flat;
-    *ox = (float)((x - grid.offset_x) - (double)sx * grid.cell_size);
-    *oy = (float)((y - grid.offset_y) - (double)sy * grid.cell_size);
-    return true;
+    if (!tile) {
+      unsigned __int128 idx = (unsigned __int128)xi * nx + yi;
+      if (idx >= ncells) return 1;
+      uint64_t flat = (uint64_t)idx;
+      uint64_t sx = flat / nx, sy = flat % nx;
+      *cell = (uint32_t)flat;
+      *ox = (float)((x - grid.offset_x) - (double)sx * grid.cell_size);
+      *oy = (float)((y - grid.offset_y) - (double)sy * grid.cell_size);
+      return 0;
+    }
+    // tiles have neighbours instead of clamp / alias edges: stay inside the global grid
+    if (!((x - grid.offset_x) >= 0.0) || !((y - grid.offset_y) >= 0.0) || xi >= gny || yi >= gnx)
+      return 1;
+    if (xi < gdev.org_x + gdev.own_x0 || xi >= gdev.org_x + gdev.own_x1 ||
+        yi < gdev.org_y + gdev.own_y0 || yi >= gdev.org_y + gdev.own_y1)
+      return 2;
+    *cell = (uint32_t)((xi - gdev.org_x) * nx + (yi - gdev.org_y));
+    *ox = (float)((x - grid.offset_x) - (double)xi * grid.cell_size);
+    *oy = (float)((y - grid.offset_y) - (double)yi * grid.cell_size);
+    return 0;
   }
   void to_global(uint32_t cell, float ox, float oy, double* x, double* y) const {
-    uint64_t sx = cell / nx, sy = cell % nx;
+    uint64_t sx = cell / nx + gdev.org_x, sy = cell % nx + gdev.org_y;
     *x = grid.offset_x + ((double)sx * grid.cell_size + (double)ox);
     *y = grid.offset_y + ((double)sy * grid.cell_size + (double)oy);
   }
@@ -1543,7 +1664,7 @@ struct cs_engine {
       if (h.alive) {
         uint32_t c;
         float ox, oy;
-        if (to_cell(h.d.source_x, h.d.source_y, &c, &ox, &oy)) {
+        if (to_cell(h.d.source_x, h.d.source_y, &c, &ox, &oy) == 0) {
           d.src_cell = c;
           d.src_ox = ox;
           d.src_oy = oy;
@@ -1597,7 +1718,7 @@ struct cs_engine {
     HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));
     if (n_slots)
       hipLaunchKernelGGL(k_count, dim3((n_slots + 255) / 256), dim3(256), 0, stream, buf[cur], 0u,
-                         n_slots, cell_count);
+                         n_slots, cell_count, ctr, gdev.tile);
     HIP_OK(hipGetLastError());
     hist_valid = true;
     return 0;
@@ -1616,7 +1737,7 @@ struct cs_engine {
     prof_begin(CS_K_SCATTER);
     if (n_slots)
       hipLaunchKernelGGL(k_scatter, dim3((n_slots + 255) / 256), dim3(256), 0, stream, buf[cur],
-                         buf[cur ^ 1], n_slots, cell_start);
+                         buf[cur ^ 1], n_slots, cell_start, ctr, gdev.tile);
     prof_end();
     HIP_OK(hipGetLastError());
     cur ^= 1;
@@ -1706,15 +1827,16 @@ struct cs_engine {
       return 4;
     }
     if (int rc = reserve((uint64_t)n_slots + n)) return rc;
-    std::vector<float2> off(n), vel(n, make_float2(0.f, 0.f));
-    std::vector<uint32_t> ids(n), cells(n), meta(n, group);
-    size_t ok = 0;
+    std::vector<float2> off, vel;
+    std::vector<uint32_t> ids, cells, meta;
+    off.reserve(n); ids.reserve(n); cells.reserve(n);
     int rc = 0;
-    for (; ok < n; ++ok) {
+    for (size_t k = 0; k < n; ++k) {
       uint32_t c;
       float ox, oy;
       uint64_t id = next_id++;  // consumed even when the insert fails (lib.rs:128-129)
-      if (!to_cell(xy[2 * ok], xy[2 * ok + 1], &c, &ox, &oy)) {
+      int where = to_cell(xy[2 * k], xy[2 * k + 1], &c, &ox, &oy);
+      if (where == 1) {
         // The reference has already put the agent into `agents` when the index insert
         // fails (lib.rs:133-149); such an agent can never be stepped, so the engine
         // drops it and reports the same error.
@@ -1722,18 +1844,22 @@ struct cs_engine {
         rc = 1;
         break;
       }
-      off[ok] = make_float2(ox, oy);
-      ids[ok] = (uint32_t)id;
-      cells[ok] = c;
-      if (out_ids) out_ids[ok] = id;
+      if (out_ids) out_ids[k] = id;
+      if (where == 2) continue;  // another tile owns it
+      off.push_back(make_float2(ox, oy));
+      ids.push_back((uint32_t)id);
+      cells.push_back(c);
       cs_event ev;
       ev.kind = CS_EVENT_SPAWNED;
       ev.source_sink = owner;
       ev.id = id;
-      ev.x = xy[2 * ok];
-      ev.y = xy[2 * ok + 1];
+      ev.x = xy[2 * k];
+      ev.y = xy[2 * k + 1];
       events.push_back(ev);
     }
+    const size_t ok = ids.size();
+    vel.assign(ok, make_float2(0.f, 0.f));
+    meta.assign(ok, group);
     if (ok) {
       AgentArrays& a = buf[cur];
       uint32_t at = n_slots;
@@ -1748,6 +1874,7 @@ struct cs_engine {
       sorted = false;
       hist_valid = false;
       occ_valid = false;
+      HIP_OK(hipMemcpy(&ctr->n_pending, &n_slots, sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     return rc;
   }
@@ -1761,7 +1888,12 @@ struct cs_engine {
     if (int rc = upload_sinks()) return rc;
     if (int rc = upload_groups()) return rc;
     const bool has_sinks = n_live_sinks > 0;
-    const bool need_host = has_sinks || any_callback_hlp || report != nullptr;
+    if (tile && has_sinks) {
+      error = "source-sinks are not supported on a tile engine yet (spawn ids need a cross-tile order)";
+      return 6;
+    }
+    // a tile's slot count changes with every halo exchange: the host re-reads it each step
+    const bool need_host = has_sinks || any_callback_hlp || report != nullptr || tile;
 
     HIP_OK(hipMemsetAsync((char*)ctr + CS_COUNTERS_PER_STEP_OFFSET, 0,
                           sizeof(Counters) - CS_COUNTERS_PER_STEP_OFFSET, stream));
@@ -1825,6 +1957,8 @@ struct cs_engine {
     if (has_sinks)
       HIP_OK(hipMemsetAsync(src_occupied, 0, std::max<size_t>(sinks.size(), 1) * sizeof(uint32_t), stream));
     HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));
+    if (tile && n_slots)  // ghosts get no thread: their output slots must read "dead"
+      HIP_OK(hipMemsetAsync(buf[cur ^ 1].cell, 0xFF, (size_t)n_slots * sizeof(uint32_t), stream));
     StepParams P;
     P.g = gdev;
     P.dt = (float)dt_seconds;
@@ -1877,7 +2011,7 @@ struct cs_engine {
       size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * entry +
                    (size_t)cfg.table_cap * 2u;
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
-                         blk_desc_cap, n_blocks_dev);
+                         blk_desc_cap, n_blocks_dev, ctr);
       uint32_t grid_blocks = (n_slots + 255u) / 256u + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
       grid_blocks = std::min(grid_blocks, blk_desc_cap);
       prof_begin(CS_K_NEIGHBOUR_FORCE);
@@ -1892,6 +2026,9 @@ struct cs_engine {
       }
       prof_end();
     } else {
+      if (tile)  // owned count + slot count of the step output
+        hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
+                           blk_desc_cap, n_blocks_dev, ctr);
       prof_begin(CS_K_NEIGHBOUR_FORCE);
       if (n_slots)
         hipLaunchKernelGGL(k_step_gather, dim3((n_slots + 255) / 256), dim3(256), 0, stream, P, buf[cur],
@@ -1930,7 +2067,12 @@ struct cs_engine {
     n_slots = c.n_alive;  // the step wrote exactly the live population
     if (int rc = finish_spawn_events(c.n_spawned, first_spawn_id)) return rc;
     if (int rc = finish_destroy_events(c)) return rc;
-    n_alive_host = (uint64_t)c.n_alive - c.n_destroyed;
+    n_alive_host = tile ? (uint64_t)c.n_owned : (uint64_t)c.n_alive - c.n_destroyed;
+    if (c.n_halo_overflow) {
+      error = "halo buffer overflow: raise capacity_records of cs_halo_set_buffers";
+      poisoned = true;
+      return 7;
+    }
     if (report) {
       report->n_agents = n_alive_host;
       report->n_spawned = c.n_spawned;
@@ -2002,6 +2144,45 @@ struct cs_engine {
     return 0;
   }
 
+  // ---- tiles: pack / unpack one axis of the halo exchange ----
+  int halo_pack(uint32_t axis) {
+    if (poisoned) {
+      error = "Index out of bounds";
+      return 1;
+    }
+    if (int rc = recount()) return rc;  // ranks of appended records extend this histogram
+    HaloDir& lo = halo[axis * 2];
+    HaloDir& hi = halo[axis * 2 + 1];
+    if (lo.send) HIP_OK(hipMemsetAsync(lo.send, 0, sizeof(HaloRecord), stream));
+    if (hi.send) HIP_OK(hipMemsetAsync(hi.send, 0, sizeof(HaloRecord), stream));
+    if ((lo.send || hi.send) && n_slots) {
+      prof_begin(CS_K_HALO);
+      hipLaunchKernelGGL(k_halo_pack, dim3((n_slots + 255) / 256), dim3(256), 0, stream, gdev, buf[cur],
+                         n_slots, axis, 2u * halo_cells, lo.send, hi.send,
+                         std::max(lo.cap, hi.cap), ctr);
+      prof_end();
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  int halo_unpack(uint32_t axis) {
+    for (int k = 0; k < 2; ++k) {
+      HaloDir& d = halo[axis * 2 + k];
+      if (!d.recv) continue;
+      if ((uint64_t)n_slots + d.cap > cap)  // the tile's population grew: reallocate (rare)
+        if (int rc = reserve((uint64_t)n_slots + d.cap)) return rc;
+      prof_begin(CS_K_HALO);
+      hipLaunchKernelGGL(k_halo_unpack, dim3((d.cap + 255) / 256), dim3(256), 0, stream, gdev, buf[cur],
+                         (uint32_t)cap, d.recv, d.cap, cell_count, ctr);
+      prof_end();
+      n_slots += d.cap;  // upper bound; kernels stop at the device-side count
+      sorted = false;
+      occ_valid = false;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+
   // make buf[cur] sorted for queries between steps
   int ensure_index() {
     if (sorted) return 0;
@@ -2046,23 +2227,57 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
     delete e;
     return nullptr;
   }
-  // (width / cell) as usize rows, (height / cell) as usize columns; the row stride
-  // is nx on both axes (location_hash_2d.rs:36-37,59)
-  e->nx = sat_usize(grid->width / grid->cell_size);
-  e->ny = sat_usize(grid->height / grid->cell_size);
-  unsigned __int128 nc = (unsigned __int128)e->nx * e->ny;
-  if (nc >= 0x7FFFFFFFull || e->nx >= 0x7FFFFFFFull) {
+  // (width / cell) as usize is the row stride, used on BOTH axes, and the number of x rows
+  // that fit is len / stride = (height / cell) as usize (location_hash_2d.rs:36-37,59)
+  e->gnx = sat_usize(grid->width / grid->cell_size);
+  e->gny = sat_usize(grid->height / grid->cell_size);
+  unsigned __int128 gnc = (unsigned __int128)e->gnx * e->gny;
+  if (gnc >= 0x7FFFFFFFull || e->gnx >= 0x7FFFFFFFull) {
     fprintf(stderr, "crowdstep: grid too large for 32-bit cell indices\n");
     delete e;
     return nullptr;
   }
-  e->ncells = (uint64_t)nc;
+  e->nx = e->gnx;
+  e->ny = e->gny;
+  std::memset(&e->gdev, 0, sizeof e->gdev);
+  uint32_t ox0 = 0, ox1 = (uint32_t)e->gny, oy0 = 0, oy1 = (uint32_t)e->gnx, org_x = 0, org_y = 0;
+  if (cfg && (cfg->tile_cx1 | cfg->tile_cy1)) {
+    const uint32_t H = cfg->halo_cells;
+    if (cfg->tile_cx0 >= cfg->tile_cx1 || cfg->tile_cy0 >= cfg->tile_cy1 || cfg->tile_cx1 > e->gny ||
+        cfg->tile_cy1 > e->gnx || H == 0) {
+      fprintf(stderr, "crowdstep: bad tile rectangle / halo_cells\n");
+      delete e;
+      return nullptr;
+    }
+    e->tile = true;
+    e->halo_cells = H;
+    const uint32_t lx0 = cfg->tile_cx0 > H ? cfg->tile_cx0 - H : 0;
+    const uint32_t ly0 = cfg->tile_cy0 > H ? cfg->tile_cy0 - H : 0;
+    const uint32_t lx1 = (uint32_t)std::min<uint64_t>(e->gny, (uint64_t)cfg->tile_cx1 + H);
+    const uint32_t ly1 = (uint32_t)std::min<uint64_t>(e->gnx, (uint64_t)cfg->tile_cy1 + H);
+    e->ny = lx1 - lx0;
+    e->nx = ly1 - ly0;
+    org_x = lx0;
+    org_y = ly0;
+    ox0 = cfg->tile_cx0 - lx0;
+    ox1 = cfg->tile_cx1 - lx0;
+    oy0 = cfg->tile_cy0 - ly0;
+    oy1 = cfg->tile_cy1 - ly0;
+  }
+  e->ncells = e->nx * e->ny;
   e->gdev.nx = (uint32_t)e->nx;
   e->gdev.ny = (uint32_t)e->ny;
   e->gdev.ncells = (uint32_t)e->ncells;
   e->gdev.cs = (float)grid->cell_size;
   e->gdev.cs_lo = (float)(grid->cell_size - (double)e->gdev.cs);
   e->gdev.inv_cs = 1.0f / e->gdev.cs;
+  e->gdev.tile = e->tile ? 1u : 0u;
+  e->gdev.own_x0 = ox0;
+  e->gdev.own_x1 = ox1;
+  e->gdev.own_y0 = oy0;
+  e->gdev.own_y1 = oy1;
+  e->gdev.org_x = org_x;
+  e->gdev.org_y = org_y;
   if (cfg && cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
@@ -2321,17 +2536,36 @@ void cs_profile_reset(cs_engine* e) {
   }
 }
 
-int cs_halo_set_buffers(cs_engine* e, uint32_t, void*, void*, uint64_t) {
-  e->error = "tiles are not enabled on this engine";
-  return 3;
+int cs_halo_set_buffers(cs_engine* e, uint32_t dir, void* send_dev, void* recv_dev,
+                        uint64_t capacity_records) {
+  hipSetDevice(e->device);
+  if (!e->tile || dir > 3 || capacity_records == 0 || capacity_records > 0x7FFFFFFFull) {
+    e->error = "halo buffers need a tile engine, a direction 0..3 and a capacity";
+    return 3;
+  }
+  e->halo[dir].send = static_cast<HaloRecord*>(send_dev);
+  e->halo[dir].recv = static_cast<HaloRecord*>(recv_dev);
+  e->halo[dir].cap = (uint32_t)capacity_records;
+  // room for everything the four neighbours may deliver in one step
+  return e->reserve((uint64_t)e->n_slots + 1024);
 }
-int cs_halo_pack(cs_engine* e, uint32_t) {
-  e->error = "tiles are not enabled on this engine";
-  return 3;
+
+int cs_halo_pack(cs_engine* e, uint32_t axis) {
+  hipSetDevice(e->device);
+  if (!e->tile || axis > 1) {
+    e->error = "tiles are not enabled on this engine";
+    return 3;
+  }
+  return e->halo_pack(axis);
 }
-int cs_halo_unpack(cs_engine* e, uint32_t) {
-  e->error = "tiles are not enabled on this engine";
-  return 3;
+
+int cs_halo_unpack(cs_engine* e, uint32_t axis) {
+  hipSetDevice(e->device);
+  if (!e->tile || axis > 1) {
+    e->error = "tiles are not enabled on this engine";
+    return 3;
+  }
+  return e->halo_unpack(axis);
 }
 
 }  // extern "C"

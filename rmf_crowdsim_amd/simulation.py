@@ -252,13 +252,14 @@ class Simulation:
     """Simulation<LocationHash2D>, lib.rs:69-383, on one MI355X."""
 
     def __init__(self, spatial_index, device=0, flags=_abi.CS_CFG_DEFAULT, capacity_hint=0,
-                 stream=None, tile=None):
+                 stream=None, tile=None, halo_cells=0):
         self._lib = self._load_library()
         grid = spatial_index._desc()
-        cfg = _abi.DeviceCfg(int(device), int(flags), 0, 0, 0, 0, int(capacity_hint),
+        cfg = _abi.DeviceCfg(int(device), int(flags), 0, 0, 0, 0, 0, 0, int(capacity_hint),
                              C.c_void_p(stream) if stream else None)
         if tile is not None:
             cfg.tile_cx0, cfg.tile_cx1, cfg.tile_cy0, cfg.tile_cy1 = [int(t) for t in tile]
+            cfg.halo_cells = int(halo_cells)
         self.spatial_index = spatial_index
         self._engine = self._lib.cs_create(C.byref(grid), C.byref(cfg))
         if not self._engine:
@@ -430,6 +431,20 @@ class Simulation:
         got = self._lib.cs_query_knn(self._engine, int(n), float(position[0]), float(position[1]),
                                      out.ctypes.data_as(C.POINTER(C.c_uint64)))
         return [int(i) for i in out[:got]]
+
+    # -- tiles (multi-GPU): halo hooks, see tiles.py --
+    def halo_set_buffers(self, direction, send_ptr, recv_ptr, capacity_records):
+        if self._lib.cs_halo_set_buffers(self._engine, int(direction), C.c_void_p(send_ptr),
+                                         C.c_void_p(recv_ptr), int(capacity_records)) != 0:
+            raise self._err()
+
+    def halo_pack(self, axis):
+        if self._lib.cs_halo_pack(self._engine, int(axis)) != 0:
+            raise self._err()
+
+    def halo_unpack(self, axis):
+        if self._lib.cs_halo_unpack(self._engine, int(axis)) != 0:
+            raise self._err()
 
     # -- measurement --
     def profile_enable(self, kernel_mask=0xFFFFFFFF):

@@ -1,0 +1,222 @@
+"""Spatial tiles: one engine per GPU, a ghost ring per tile, a two-phase halo exchange.
+
+The reference is a single process; this is the multi-GPU row of the hot path.
+The global LocationHash2D grid is cut into tiles_x x tiles_y rectangles of whole cells.  Every
+tile engine owns the agents whose cell lies in its rectangle and keeps `halo_cells` ghost
+cells around it.  Per step:
+
+    pack X -> exchange with the X neighbours -> unpack X      (cs_halo_pack / cs_halo_unpack)
+    pack Y -> exchange with the Y neighbours -> unpack Y      (Y carries what arrived in X,
+                                                               so corners reach diagonal tiles)
+    cs_step on every tile
+
+Two transports move the fixed-capacity device buffers:
+    LocalTileMesh      several tiles in ONE process on one GPU (device-to-device copies);
+                       the test double of the multi-GPU logic on a single-GPU box
+    DistributedTiles   one rank per GPU under torch.distributed (backend "nccl" = RCCL over
+                       xGMI; "gloo" with CPU tensors in the transport tests)
+"""
+import numpy as np
+
+from . import _abi
+from .simulation import LocationHash2D, Simulation
+
+XLO, XHI, YLO, YHI = _abi.CS_DIR_XLO, _abi.CS_DIR_XHI, _abi.CS_DIR_YLO, _abi.CS_DIR_YHI
+OPPOSITE = {XLO: XHI, XHI: XLO, YLO: YHI, YHI: YLO}
+RECORD = _abi.CS_HALO_RECORD_BYTES
+
+
+class TileLayout:
+    """Even split of the global cell grid.  `x` is the index that location_to_index multiplies
+    by the row stride (location_hash_2d.rs:59); there are (height / cell) x-rows of
+    (width / cell) cells each."""
+
+    def __init__(self, spatial_index, tiles_x, tiles_y):
+        self.cols = int(spatial_index.width / spatial_index.cell_size)   # stride, y cells per row
+        self.rows = int(spatial_index.height / spatial_index.cell_size)  # x rows
+        self.tiles_x, self.tiles_y = int(tiles_x), int(tiles_y)
+        self.x_edges = [round(k * self.rows / self.tiles_x) for k in range(self.tiles_x + 1)]
+        self.y_edges = [round(k * self.cols / self.tiles_y) for k in range(self.tiles_y + 1)]
+
+    @property
+    def n_tiles(self):
+        return self.tiles_x * self.tiles_y
+
+    def coords(self, index):
+        return index // self.tiles_y, index % self.tiles_y
+
+    def index(self, tx, ty):
+        return tx * self.tiles_y + ty
+
+    def rect(self, tx, ty):
+        return (self.x_edges[tx], self.x_edges[tx + 1], self.y_edges[ty], self.y_edges[ty + 1])
+
+    def neighbour(self, tx, ty, direction):
+        dx, dy = {XLO: (-1, 0), XHI: (1, 0), YLO: (0, -1), YHI: (0, 1)}[direction]
+        nx, ny = tx + dx, ty + dy
+        if 0 <= nx < self.tiles_x and 0 <= ny < self.tiles_y:
+            return self.index(nx, ny)
+        return None
+
+    def min_tile_cells(self):
+        return min(min(np.diff(self.x_edges)), min(np.diff(self.y_edges)))
+
+
+def default_tiling(n):
+    """4 x 2 for 8 GPUs (BASELINE.json configs[2]), the squarest split otherwise."""
+    best = (n, 1)
+    for a in range(1, n + 1):
+        if n % a == 0 and a >= n // a:
+            best = (a, n // a)
+            break
+    return best
+
+
+def halo_capacity(layout, density_per_cell, halo_cells, slack=2.0):
+    """Records per direction, the same on every tile (both ends of a link must agree): a band
+    of 2*halo cells along the longest tile edge, with slack."""
+    edge = max(max(np.diff(layout.x_edges)), max(np.diff(layout.y_edges))) + 4 * halo_cells
+    return int(max(1024, slack * density_per_cell * edge * 2 * halo_cells))
+
+
+class _TileBase:
+    def _make_engine(self, spatial_index, layout, index, halo_cells, device, stream, capacity_hint,
+                     flags):
+        tx, ty = layout.coords(index)
+        return Simulation(spatial_index, device=device, flags=flags, capacity_hint=capacity_hint,
+                          stream=stream, tile=layout.rect(tx, ty), halo_cells=halo_cells)
+
+    @staticmethod
+    def _alloc(torch, n_records, device):
+        return torch.zeros((n_records + 1) * RECORD, dtype=torch.uint8, device=device)
+
+
+class LocalTileMesh(_TileBase):
+    """All tiles of a layout in one process on one GPU.  Exchanges are device-to-device copies
+    on the shared stream.  Same engine code path as one-rank-per-GPU."""
+
+    def __init__(self, spatial_index, tiles, halo_cells, device=0, capacity_records=None,
+                 density_per_cell=16.0, flags=0):
+        import torch
+        self.torch = torch
+        self.layout = TileLayout(spatial_index, *tiles)
+        self.halo_cells = int(halo_cells)
+        assert self.layout.min_tile_cells() >= 2 * self.halo_cells, "tiles thinner than two halos"
+        dev = torch.device("cuda", device)
+        # engines and buffer copies must share ONE real stream: torch's default stream has handle 0,
+        # which the engine reads as "create your own", and then nothing orders pack -> copy -> unpack
+        self.stream = torch.cuda.Stream(dev)
+        stream = self.stream.cuda_stream
+        self.engines, self.bufs = [], []
+        for index in range(self.layout.n_tiles):
+            sim = self._make_engine(spatial_index, self.layout, index, halo_cells, device, stream, 0,
+                                    flags)
+            tx, ty = self.layout.coords(index)
+            cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
+            bufs = {}
+            for d in (XLO, XHI, YLO, YHI):
+                if self.layout.neighbour(tx, ty, d) is None:
+                    continue
+                send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
+                sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
+                bufs[d] = (send, recv)
+            self.engines.append(sim)
+            self.bufs.append(bufs)
+        torch.cuda.synchronize(dev)  # the zero fills ran on the default stream
+
+    def add_agents(self, positions, high_level_planner, local_planner, eyesight):
+        ids = None
+        for sim in self.engines:  # every tile sees the global list and keeps what it owns
+            ids = sim.add_agents(positions, high_level_planner, local_planner, eyesight)
+        return ids
+
+    def _exchange(self, axis):
+        for sim in self.engines:
+            sim.halo_pack(axis)
+        with self.torch.cuda.stream(self.stream):
+            for index, bufs in enumerate(self.bufs):
+                tx, ty = self.layout.coords(index)
+                for d in ((XLO, XHI) if axis == 0 else (YLO, YHI)):
+                    if d not in bufs:
+                        continue
+                    peer = self.layout.neighbour(tx, ty, d)
+                    self.bufs[peer][OPPOSITE[d]][1].copy_(bufs[d][0], non_blocking=True)
+        for sim in self.engines:
+            sim.halo_unpack(axis)
+
+    def step(self, dur, report=True):
+        self._exchange(0)
+        self._exchange(1)
+        for sim in self.engines:
+            sim.step(dur, report=report)
+
+    def read_agents(self):
+        parts = [sim.read_agents() for sim in self.engines]
+        out = np.concatenate(parts)
+        return out[np.argsort(out["id"], kind="stable")]
+
+    def __len__(self):
+        return sum(len(sim) for sim in self.engines)
+
+
+def exchange_axis(dist, layout, index, bufs, axis):
+    """One phase of the exchange for the tile `index` = this rank: post the sends of this axis
+    and the matching receives as one batch (P2P over xGMI with the nccl/RCCL backend)."""
+    tx, ty = layout.coords(index)
+    ops = []
+    for d in ((XLO, XHI) if axis == 0 else (YLO, YHI)):
+        peer = layout.neighbour(tx, ty, d)
+        if peer is None:
+            continue
+        send, recv = bufs[d]
+        ops.append(dist.P2POp(dist.isend, send, peer))
+        ops.append(dist.P2POp(dist.irecv, recv, peer))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+
+class DistributedTiles(_TileBase):
+    """One tile per rank (rank == tile index) under an initialised torch.distributed group."""
+
+    def __init__(self, spatial_index, tiles, halo_cells, device, capacity_records=None,
+                 density_per_cell=16.0, capacity_hint=0, flags=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.layout = TileLayout(spatial_index, *tiles)
+        assert self.layout.n_tiles == dist.get_world_size(), "one rank per tile"
+        assert self.layout.min_tile_cells() >= 2 * int(halo_cells), "tiles thinner than two halos"
+        self.index = dist.get_rank()
+        dev = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(dev)  # shared by the engine and the P2P ops (see LocalTileMesh)
+        stream = self.stream.cuda_stream
+        self.sim = self._make_engine(spatial_index, self.layout, self.index, halo_cells, device, stream,
+                                     capacity_hint, flags)
+        tx, ty = self.layout.coords(self.index)
+        cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
+        self.bufs = {}
+        for d in (XLO, XHI, YLO, YHI):
+            if self.layout.neighbour(tx, ty, d) is None:
+                continue
+            send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
+            self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
+            self.bufs[d] = (send, recv)
+        torch.cuda.synchronize(dev)
+
+    def add_agents(self, positions, high_level_planner, local_planner, eyesight):
+        return self.sim.add_agents(positions, high_level_planner, local_planner, eyesight)
+
+    def step(self, dur, report=False):
+        with self.torch.cuda.stream(self.stream):
+            for axis in (0, 1):
+                self.sim.halo_pack(axis)
+                exchange_axis(self.dist, self.layout, self.index, self.bufs, axis)
+                self.sim.halo_unpack(axis)
+        self.sim.step(dur, report=report)
+
+    def read_agents(self):
+        return self.sim.read_agents()
+
+    def __len__(self):
+        return len(self.sim)
