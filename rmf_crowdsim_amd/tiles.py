@@ -163,17 +163,24 @@ def exchange_axis(dist, layout, index, bufs, axis):
     """One phase of the exchange for the tile `index` = this rank: post the sends of this axis
     and the matching receives as one batch (P2P over xGMI with the nccl/RCCL backend)."""
     tx, ty = layout.coords(index)
-    ops = []
+    ops, staged = [], []
     for d in ((XLO, XHI) if axis == 0 else (YLO, YHI)):
         peer = layout.neighbour(tx, ty, d)
         if peer is None:
             continue
         send, recv = bufs[d]
+        if send.is_cuda and dist.get_backend() == "gloo":
+            # test transport (several ranks sharing one GPU): gloo moves host memory
+            host_recv = recv.cpu()
+            staged.append((recv, host_recv))
+            send, recv = send.cpu(), host_recv
         ops.append(dist.P2POp(dist.isend, send, peer))
         ops.append(dist.P2POp(dist.irecv, recv, peer))
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+    for dev_recv, host_recv in staged:
+        dev_recv.copy_(host_recv)
 
 
 class DistributedTiles(_TileBase):

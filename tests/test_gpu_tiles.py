@@ -75,3 +75,55 @@ def test_creeping_counterflow_across_tiles():
     force = np.hypot(a["vx"], np.abs(a["vy"]) - scenes.CREEP_SPEED)
     assert np.mean(force > 0) > 0.9
     assert a.tobytes() == b.tobytes()
+
+
+# ---- one rank per tile, two processes sharing the one GPU of the test box ----------------
+def _rank_main(rank, world, port, out_path):
+    import os
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from rmf_crowdsim_amd.tiles import DistributedTiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 20000
+        pts, grid, extent, group = scenes.uniform_crowd(n, seed=13, cell_size=2.0, margin=20.0)
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        tiles = DistributedTiles(LocationHash2D(**grid), (2, 1), halo_cells=1, device=0)
+        _populate(tiles, pts, group, [(1.30, 0.4), (1.28, 0.4)], lp, 2.0)
+        for _ in range(40):
+            tiles.step(0.05)
+        mine = tiles.read_agents()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            both = np.concatenate(gathered)
+            both = both[np.argsort(both["id"], kind="stable")]
+            with open(out_path, "wb") as f:
+                pickle.dump(both, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_tiles_two_ranks(tmp_path):
+    import pickle
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "ranks.pkl")
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29721, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    both = pickle.load(open(out, "rb"))
+    n = 20000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=13, cell_size=2.0, margin=20.0)
+    single = Simulation(LocationHash2D(**grid))
+    _populate(single, pts, group, [(1.30, 0.4), (1.28, 0.4)], Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+    for _ in range(40):
+        single.step(0.05, report=False)
+    a = single.read_agents()
+    assert len(both) == n and a.tobytes() == both.tobytes()
