@@ -161,6 +161,18 @@ def main():
     alg_bytes = args.agents * (K4_READ_BYTES + K4_WRITE_BYTES) + 4 * ncells
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
 
+    # HBM traffic of the kernel from the PMC counters (separate rocprofv3 passes, FETCH_SIZE x2 on
+    # gfx950): measured offline for the default workload and kept under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "k4_traffic.json")) as f:
+            tr = json.load(f)
+        if (tr["agents"], tr["cell"], tr["eyesight"]) == (args.agents, args.cell, args.eyesight) \
+                and args.kernel != "gather" and not args.debug:
+            traffic = tr["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "agent-steps/sec at 1M agents, dt=0.05 s; % HBM roofline on Zanlungo kernel",
@@ -189,7 +201,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "note": "HBM is the nominal bound of a neighbour gather; the kernel is VALU-issue / "
+                        "LDS-latency bound at this neighbour count (DESIGN.md section 4)",
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
                 "kernel_ms": k4_ms, "algorithmic_bytes_per_launch": alg_bytes,
             },

@@ -448,23 +448,29 @@ __global__ void k_scatter(AgentArrays src, AgentArrays dst, uint32_t n,
 
 // One returning atomic per distinct cell per wave instead of one per agent: the lanes that
 // share a cell elect a leader, which reserves popcount(lanes) slots; rank = base + lane order.
+// Groups are found first (ALU only), then every leader issues its atomic at once, so a wave
+// pays one atomic latency, not one per distinct cell.
 __device__ __forceinline__ uint32_t wave_histogram_rank(uint32_t* __restrict__ cell_count,
                                                         uint32_t cell, bool valid) {
   const int lane = __lane_id();
-  uint32_t rank = 0;
+  int leader = lane;
+  unsigned long long group = 0;
   unsigned long long todo = __ballot(valid);
   while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t c = __shfl(cell, leader, 64);
+    const int first = __ffsll((long long)todo) - 1;
+    const uint32_t c = __shfl(cell, first, 64);
     const bool same = valid && cell == c;
     const unsigned long long m = __ballot(same);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&cell_count[c], (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (same) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (same) {
+      leader = first;
+      group = m;
+    }
     todo &= ~m;
   }
-  return rank;
+  uint32_t base = 0;
+  if (valid && lane == leader) base = atomicAdd(&cell_count[cell], (uint32_t)__popcll(group));
+  base = __shfl(base, leader, 64);
+  return base + (uint32_t)__popcll(group & ((1ull << lane) - 1ull));
 }
 
 // ---------------------------------------------------------------------------
@@ -910,7 +916,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   float2* __restrict__ s_off = reinterpret_cast<float2*>(smem);
   float2* __restrict__ s_vel = s_off + cfg.agents_cap;
   uint32_t* __restrict__ s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
-  entry_t* __restrict__ s_list = reinterpret_cast<entry_t*>(s_id + cfg.agents_cap);  // [cap][256]
+  uint32_t* __restrict__ s_idtmp = s_id + cfg.agents_cap;  // ids in arrival order (staging only)
+  entry_t* __restrict__ s_list = reinterpret_cast<entry_t*>(s_idtmp + cfg.agents_cap);  // [cap][256]
   unsigned short* __restrict__ s_tab =
       reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
 
@@ -951,19 +958,28 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       for (int y = tid; y < W1; y += TILE_THREADS)
         s_tab[k * W1 + y] = (unsigned short)(s_base[k] + (cell_start[rowbase + y] - s_g0[k]));
     }
+    // ids first, in arrival (= global) order, so the rank of an agent inside its cell can be
+    // counted from LDS
+    for (uint32_t s = tid; s < S; s += TILE_THREADS) {
+      int k = 0;
+      while (s >= s_base[k + 1]) ++k;
+      s_idtmp[s] = in.id[s_g0[k] + (s - s_base[k])];
+    }
+    __syncthreads();
     // agents, each placed at its cell's first slot + its rank by id inside the cell
     for (uint32_t s = tid; s < S; s += TILE_THREADS) {
       int k = 0;
       while (s >= s_base[k + 1]) ++k;
       const uint32_t j = s_g0[k] + (s - s_base[k]);
-      const uint32_t cj = in.cell[j];
-      const uint32_t idj = in.id[j];
-      const uint32_t cb = cell_start[cj], ce = cell_start[cj + 1];
+      const int cy = (int)(in.cell[j] - (uint32_t)(r0 + k) * g.nx) - sy0;
+      const uint32_t idj = s_idtmp[s];
+      const unsigned short* t = s_tab + k * W1 + cy;
+      const uint32_t tb = t[0], te = t[1];
       uint32_t rank = 0;
-      if (cfg.debug & 2u) rank = j - cb;
+      if (cfg.debug & 2u) rank = s - tb;
       else
-        for (uint32_t q = cb; q < ce; ++q) rank += (in.id[q] < idj) ? 1u : 0u;
-      const uint32_t slot = s_base[k] + (cb - s_g0[k]) + rank;
+        for (uint32_t q = tb; q < te; ++q) rank += (s_idtmp[q] < idj) ? 1u : 0u;
+      const uint32_t slot = tb + rank;
       s_off[slot] = in.off[j];
       s_vel[slot] = in.vel[j];
       s_id[slot] = idj;
@@ -1048,17 +1064,41 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       rpx = oj.x - oix;
       rpy = oj.y - oiy;
     };
-    // pass 2 over the first `n` entries of the list: t_i and the right-of-way mask
+    // pass 2 over the first `n` entries of the list: t_i and the right-of-way mask.
+    // Two entries per trip: their LDS reads are issued together, so one latency covers both.
     auto run_ttc = [&](uint32_t n) {
       unsigned long long m = 0;
-      for (uint32_t k = 0; k < n; ++k) {
+      uint32_t k = 0;
+      for (; k + 1 < n; k += 2) {
+        const entry_t e0 = my_list[k * TILE_THREADS], e1 = my_list[(k + 1) * TILE_THREADS];
+        uint32_t j0, j1;
+        float fdx0, fdy0, fdx1, fdy1;
+        LE::unpack(e0, j0, fdx0, fdy0);
+        LE::unpack(e1, j1, fdx1, fdy1);
+        const float2 oj0 = s_off[j0], oj1 = s_off[j1];
+        const float2 vj0 = s_vel[j0], vj1 = s_vel[j1];
+        const uint32_t id0 = s_id[j0], id1 = s_id[j1];
+        const float rpx0 = oj0.x - __builtin_fmaf(-fdx0, g.cs, o.off.x);
+        const float rpy0 = oj0.y - __builtin_fmaf(-fdy0, g.cs, o.off.y);
+        const float rpx1 = oj1.x - __builtin_fmaf(-fdx1, g.cs, o.off.x);
+        const float rpy1 = oj1.y - __builtin_fmaf(-fdy1, g.cs, o.off.y);
+        const float t0 = ttc_f32(vj0.x - o.v.x, vj0.y - o.v.y, rpx0, rpy0,
+                                 __builtin_fmaf(rpx0, rpx0, rpy0 * rpy0), R2);
+        const float t1 = ttc_f32(vj1.x - o.v.x, vj1.y - o.v.y, rpx1, rpy1,
+                                 __builtin_fmaf(rpx1, rpx1, rpy1 * rpy1), R2);
+        T = (t0 < T) ? t0 : T;
+        T = (t1 < T) ? t1 : T;
+        const bool f0 = id0 > o.id, f1 = id1 > o.id;
+        m |= (f0 ? (1ull << k) : 0ull) | (f1 ? (2ull << k) : 0ull);
+        n_back += (f0 ? 0u : 1u) + (f1 ? 0u : 1u);
+      }
+      if (k < n) {
         uint32_t j;
         float rpx, rpy;
         rel(my_list[k * TILE_THREADS], j, rpx, rpy);
         const float2 vj = s_vel[j];
         const uint32_t idj = s_id[j];
-        const float d2 = __builtin_fmaf(rpx, rpx, rpy * rpy);
-        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, d2, R2);
+        const float t = ttc_f32(vj.x - o.v.x, vj.y - o.v.y, rpx, rpy, __builtin_fmaf(rpx, rpx, rpy * rpy), R2);
         T = (t < T) ? t : T;
         const bool f = idj > o.id;
         m |= f ? (1ull << k) : 0ull;
@@ -1097,7 +1137,28 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
             e = t[1];
           }
           const float oiy = __builtin_fmaf(-(float)dy, g.cs, o.off.y);
+          if (cfg.debug & 16u) j = e;
           while (__any(j < e)) {
+            // two candidates per trip while there is room for both: one LDS latency for two tests
+            while (j + 1 < e && cnt + 1 < CAP) {
+              const float2 oa = s_off[j], ob = s_off[j + 1];
+              const float ax = oa.x - oix, ay = oa.y - oiy, bx = ob.x - oix, by = ob.y - oiy;
+              bool ta = __builtin_fmaf(ax, ax, ay * ay) < r2 && j != self_slot;
+              bool tb = __builtin_fmaf(bx, bx, by * by) < r2 && j + 1 != self_slot;
+              if (FORCE) {
+                if (ta) ta = s_id[j] > o.id;
+                if (tb) tb = s_id[j + 1] > o.id;
+              }
+              if (ta) {
+                my_list[cnt * TILE_THREADS] = LE::make(j, dx, dy);
+                ++cnt;
+              }
+              if (tb) {
+                my_list[cnt * TILE_THREADS] = LE::make(j + 1, dx, dy);
+                ++cnt;
+              }
+              j += 2;
+            }
             while (j < e && cnt < CAP) {
               const float2 oj = s_off[j];
               const float rpx = oj.x - oix, rpy = oj.y - oiy;
@@ -1125,6 +1186,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     };
 
     sweep(false);
+    if (cfg.debug & 8u) cnt = 0;
     run_ttc(cnt);
     const bool tz = (T == 0.0f);
     if (mine && T != f_inf()) fc = make_force_ctx(o.v.x, o.v.y, T, grp);
@@ -1999,7 +2061,7 @@ struct cs_engine {
       cfg.table_cap = 1024u * (uint32_t)(h > 1 ? 2 : 1);
       const bool e16 = h <= 1 && cfg.agents_cap <= 4096u;
       const size_t entry = e16 ? 2u : 4u;
-      const size_t fixed = (size_t)cfg.agents_cap * 20u + (size_t)cfg.table_cap * 2u + 256u;
+      const size_t fixed = (size_t)cfg.agents_cap * 24u + (size_t)cfg.table_cap * 2u + 256u;
       const size_t budget = (size_t)(160u * 1024u) / std::max(1u, tile_blocks_per_cu);
       cfg.list_cap = tile_list_cap;
       if (!cfg.list_cap) {
@@ -2008,7 +2070,7 @@ struct cs_engine {
           cfg.list_cap += 8u;
       }
       cfg.list_cap = std::min(cfg.list_cap, 64u);
-      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * entry +
+      size_t lds = (size_t)cfg.agents_cap * 24u + (size_t)cfg.list_cap * TILE_THREADS * entry +
                    (size_t)cfg.table_cap * 2u;
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
                          blk_desc_cap, n_blocks_dev, ctr);
