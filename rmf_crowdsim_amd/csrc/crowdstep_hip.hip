@@ -78,18 +78,18 @@ struct Counters {
   uint32_t n_out_of_bounds;  // cumulative: any non-zero value poisons the engine
   uint32_t n_owned;          // agents in the owned rectangle (tile mode; else = n_alive)
   uint32_t n_pending;        // slots in use in the unsorted buffer (halo unpack appends)
-  // per step (zeroed before each step)
+  // written before the re-sort of a step (zeroed by the host when sinks / tiles exist)
+  uint32_t n_spawned;
+  uint32_t n_halo_overflow;
+  // written by the step kernel (zeroed by the scan of the same step)
   uint32_t n_destroyed;
   uint32_t n_waypoint_hits;
   uint32_t n_tti_zero;
   uint32_t n_nonfinite;
   uint32_t n_clamped;
-  uint32_t n_spawned;
   uint32_t n_wp_events;
-  uint32_t n_halo_overflow;
   uint32_t pad[4];
 };
-#define CS_COUNTERS_PER_STEP_OFFSET (4 * sizeof(uint32_t))
 
 struct AgentArrays {
   float2* off;
@@ -425,6 +425,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
     cell_start[ncells] = total;
     ctr->n_alive = total;
     ctr->n_owned = total;
+    ctr->n_destroyed = 0;  // the step kernel that follows counts into these
+    ctr->n_waypoint_hits = 0;
+    ctr->n_tti_zero = 0;
+    ctr->n_nonfinite = 0;
+    ctr->n_clamped = 0;
+    ctr->n_wp_events = 0;
   }
 }
 
@@ -916,8 +922,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   float2* __restrict__ s_off = reinterpret_cast<float2*>(smem);
   float2* __restrict__ s_vel = s_off + cfg.agents_cap;
   uint32_t* __restrict__ s_id = reinterpret_cast<uint32_t*>(s_vel + cfg.agents_cap);
-  uint32_t* __restrict__ s_idtmp = s_id + cfg.agents_cap;  // ids in arrival order (staging only)
-  entry_t* __restrict__ s_list = reinterpret_cast<entry_t*>(s_idtmp + cfg.agents_cap);  // [cap][256]
+  entry_t* __restrict__ s_list = reinterpret_cast<entry_t*>(s_id + cfg.agents_cap);  // [cap][256]
+  // ids in arrival order, needed only while staging: they borrow the (still unused) list area
+  uint32_t* __restrict__ s_idtmp = reinterpret_cast<uint32_t*>(s_list);
   unsigned short* __restrict__ s_tab =
       reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
 
@@ -1149,14 +1156,11 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
                 if (ta) ta = s_id[j] > o.id;
                 if (tb) tb = s_id[j + 1] > o.id;
               }
-              if (ta) {
-                my_list[cnt * TILE_THREADS] = LE::make(j, dx, dy);
-                ++cnt;
-              }
-              if (tb) {
-                my_list[cnt * TILE_THREADS] = LE::make(j + 1, dx, dy);
-                ++cnt;
-              }
+              // branch-free append: a rejected entry is overwritten by the next store
+              my_list[cnt * TILE_THREADS] = LE::make(j, dx, dy);
+              cnt += ta ? 1u : 0u;
+              my_list[cnt * TILE_THREADS] = LE::make(j + 1, dx, dy);
+              cnt += tb ? 1u : 0u;
               j += 2;
             }
             while (j < e && cnt < CAP) {
@@ -1498,6 +1502,7 @@ struct cs_engine {
   double max_eyesight = 0.0;
   uint32_t tile_blocks_per_cu = 3;  // LDS budget target of the tiled kernel (tuning knobs)
   uint32_t tile_list_cap = 0;       // 0 = derive from the budget
+  uint32_t tile_agents_slack = 0;
 
   // planners as data
   std::vector<cs_zanlungo_params> lp_params;
@@ -1957,8 +1962,8 @@ struct cs_engine {
     // a tile's slot count changes with every halo exchange: the host re-reads it each step
     const bool need_host = has_sinks || any_callback_hlp || report != nullptr || tile;
 
-    HIP_OK(hipMemsetAsync((char*)ctr + CS_COUNTERS_PER_STEP_OFFSET, 0,
-                          sizeof(Counters) - CS_COUNTERS_PER_STEP_OFFSET, stream));
+    if (has_sinks)  // n_spawned (n_halo_overflow is sticky: it poisons the tile)
+      HIP_OK(hipMemsetAsync(&ctr->n_spawned, 0, sizeof(uint32_t), stream));
 
     // ---- Phase A: spawn (lib.rs:199-254) ----
     uint32_t n_want = 0;
@@ -2009,6 +2014,8 @@ struct cs_engine {
     }
 
     // ---- index for this step (location_hash_2d.rs:126-149) ----
+    if (sorted)  // no re-sort this step: the scan is what normally zeroes the step counters
+      HIP_OK(hipMemsetAsync(&ctr->n_destroyed, 0, 6 * sizeof(uint32_t), stream));
     if (int rc = rebuild()) return rc;
 
     // ---- HighLevelPlanner callbacks (slow path) ----
@@ -2018,7 +2025,7 @@ struct cs_engine {
     // ---- Phases B + C: per-agent update and commit (lib.rs:259-359) ----
     if (has_sinks)
       HIP_OK(hipMemsetAsync(src_occupied, 0, std::max<size_t>(sinks.size(), 1) * sizeof(uint32_t), stream));
-    HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));
+    // cell_count is all zero here: the scan clears it while reading (k_scan_apply)
     if (tile && n_slots)  // ghosts get no thread: their output slots must read "dead"
       HIP_OK(hipMemsetAsync(buf[cur ^ 1].cell, 0xFF, (size_t)n_slots * sizeof(uint32_t), stream));
     StepParams P;
@@ -2057,11 +2064,11 @@ struct cs_engine {
       // LDS budget per workgroup: staged agents (20 B each, ~(2h+1) strips of 256 + halo ends),
       // the cell table and the per-thread neighbour lists; sized so that `tile_blocks_per_cu`
       // workgroups fit in the 160 KiB of a CU
-      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 9u / 8u + 192u + 63u) & ~63u);
+      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 9u / 8u + 192u + tile_agents_slack + 63u) & ~63u);
       cfg.table_cap = 1024u * (uint32_t)(h > 1 ? 2 : 1);
       const bool e16 = h <= 1 && cfg.agents_cap <= 4096u;
       const size_t entry = e16 ? 2u : 4u;
-      const size_t fixed = (size_t)cfg.agents_cap * 24u + (size_t)cfg.table_cap * 2u + 256u;
+      const size_t fixed = (size_t)cfg.agents_cap * 20u + (size_t)cfg.table_cap * 2u + 256u;
       const size_t budget = (size_t)(160u * 1024u) / std::max(1u, tile_blocks_per_cu);
       cfg.list_cap = tile_list_cap;
       if (!cfg.list_cap) {
@@ -2070,7 +2077,8 @@ struct cs_engine {
           cfg.list_cap += 8u;
       }
       cfg.list_cap = std::min(cfg.list_cap, 64u);
-      size_t lds = (size_t)cfg.agents_cap * 24u + (size_t)cfg.list_cap * TILE_THREADS * entry +
+      while ((size_t)cfg.list_cap * TILE_THREADS * entry < (size_t)cfg.agents_cap * 4u) cfg.list_cap += 8u;
+      size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * entry +
                    (size_t)cfg.table_cap * 2u;
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
                          blk_desc_cap, n_blocks_dev, ctr);
@@ -2114,6 +2122,7 @@ struct cs_engine {
       // "Index out of bounds" (location_hash_2d.rs:61-63 via lib.rs:299-302): nothing is
       // committed; the pre-step state (including this step's spawns) stays current.
       HIP_OK(hipMemsetAsync(&ctr->n_out_of_bounds, 0, sizeof(uint32_t), stream));
+      HIP_OK(hipMemsetAsync(cell_count, 0, (ncells + 1) * sizeof(uint32_t), stream));  // partial histogram
       hist_valid = false;
       occ_valid = false;
       n_alive_host = c.n_alive;
@@ -2357,6 +2366,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
     (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
   bool ok = true;
   ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
