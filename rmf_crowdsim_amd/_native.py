@@ -47,7 +47,8 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH]
+    extra = os.environ.get("CS_HIPCC_EXTRA", "").split()
+    cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -798,6 +798,10 @@ __global__ void __launch_bounds__(256) k_step_gather(StepParams P, AgentArrays i
 // consecutive agents of ONE grid row, so the cells it must see are (2h+1)
 // contiguous ranges of the sorted arrays.  Built on the device after the scan.
 // ---------------------------------------------------------------------------
+#ifndef TILE_THREADS
+#define TILE_THREADS 256  // agents (= threads) per workgroup of the tiled neighbour kernel
+#endif
+
 struct BlockDesc {
   uint32_t row, first, count;
 };
@@ -823,7 +827,7 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
       first = cell_start[(unsigned long long)R * g.nx + g.own_y0];
       cnt = cell_start[(unsigned long long)R * g.nx + g.own_y1] - first;
     }
-    uint32_t nb = (cnt + 255u) / 256u;
+    uint32_t nb = (cnt + TILE_THREADS - 1u) / TILE_THREADS;
     uint32_t incl = wave_incl_scan(nb, lane);
     if (lane == 63) wsum[wave] = incl;
     if (cnt) atomicAdd(&s_owned, cnt);
@@ -835,8 +839,8 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
       if (excl + k < desc_cap) {
         BlockDesc d;
         d.row = R;
-        d.first = first + k * 256u;
-        d.count = min(256u, cnt - k * 256u);
+        d.first = first + k * TILE_THREADS;
+        d.count = min((uint32_t)TILE_THREADS, cnt - k * TILE_THREADS);
         desc[excl + k] = d;
       }
     }
@@ -853,7 +857,6 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
 }
 
 #define TILE_MAX_ROWS 17  // 2 * 8 + 1: eyesight up to 8 cells
-#define TILE_THREADS 256
 
 struct TileCfg {
   int h;                // ceil(max eyesight / cell)
@@ -1588,7 +1591,7 @@ struct cs_engine {
     wp_events_cap = (uint32_t)ncap;
     HIP_OK(hipMalloc(&wp_events, (uint64_t)wp_events_cap * sizeof(uint2)));
     hipFree(blk_desc);
-    blk_desc_cap = (uint32_t)(ncap / 256 + ncells / std::max<uint64_t>(nx, 1) + 8);
+    blk_desc_cap = (uint32_t)(ncap / TILE_THREADS + ncells / std::max<uint64_t>(nx, 1) + 8);
     HIP_OK(hipMalloc(&blk_desc, (uint64_t)blk_desc_cap * sizeof(BlockDesc)));
     if (!n_blocks_dev) HIP_OK(hipMalloc(&n_blocks_dev, sizeof(uint32_t)));
     cap = ncap;
@@ -2064,7 +2067,7 @@ struct cs_engine {
       // LDS budget per workgroup: staged agents (20 B each, ~(2h+1) strips of 256 + halo ends),
       // the cell table and the per-thread neighbour lists; sized so that `tile_blocks_per_cu`
       // workgroups fit in the 160 KiB of a CU
-      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * 256u * 9u / 8u + 192u + tile_agents_slack + 63u) & ~63u);
+      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * TILE_THREADS * 9u / 8u + 192u + tile_agents_slack + 63u) & ~63u);
       cfg.table_cap = 1024u * (uint32_t)(h > 1 ? 2 : 1);
       const bool e16 = h <= 1 && cfg.agents_cap <= 4096u;
       const size_t entry = e16 ? 2u : 4u;
@@ -2082,7 +2085,7 @@ struct cs_engine {
                    (size_t)cfg.table_cap * 2u;
       hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
                          blk_desc_cap, n_blocks_dev, ctr);
-      uint32_t grid_blocks = (n_slots + 255u) / 256u + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
+      uint32_t grid_blocks = (n_slots + TILE_THREADS - 1u) / TILE_THREADS + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
       grid_blocks = std::min(grid_blocks, blk_desc_cap);
       prof_begin(CS_K_NEIGHBOUR_FORCE);
       if (n_slots)
