@@ -1,0 +1,278 @@
+// crowdsim.hpp — C++ host-side mirror of the reference's trait surface over the C ABI.
+//
+// Same names, argument order and error behaviour as rmf_crowdsim (paths relative to
+// rmf_crowdsim/src in the reference tree); Result<_, String> becomes std::runtime_error(message).
+//   Simulation            lib.rs:69-383            EventListener     lib.rs:22-33
+//   HighLevelPlanner      highlevel_planners/highlevel_planners.rs:8-16
+//   LocalPlanner / Zanlungo / NoLocalPlan   local_planners/{local_planner,zanlungo,no_local_plan}.rs
+//   LocationHash2D        spatial_index/location_hash_2d.rs:33-51
+//   SourceSink / CrowdGenerator / MonotonicCrowd      source_sink/source_sink.rs:30-101
+// Header-only; link against libcrowdstep_hip.so (the HIP engine).  There is no CPU path.
+#ifndef CROWDSIM_HPP
+#define CROWDSIM_HPP
+
+#include <chrono>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "crowdstep.h"
+
+namespace rmf_crowdsim {
+
+using AgentId = std::size_t;  // lib.rs:36
+struct Vec2f {               // lib.rs:40-43 (nalgebra Vector2<f64>)
+  double x = 0, y = 0;
+};
+using Point = Vec2f;
+
+struct Agent {  // lib.rs:46-65
+  AgentId agent_id = 0;
+  Point position;
+  double orientation = 0;
+  Vec2f velocity;
+  double angular_vel = 0;
+  std::size_t next_waypoint = 0;
+  double eyesight_range = 0;
+};
+
+struct EventListener {  // lib.rs:22-33
+  virtual ~EventListener() = default;
+  virtual void agent_spawned(Vec2f position, AgentId agent) = 0;
+  virtual void agent_destroyed(AgentId agent) = 0;
+  virtual void waypoint_reached(Vec2f, AgentId) {}
+};
+
+struct LocationHash2D {  // location_hash_2d.rs:33
+  double width, height, cell_size;
+  Point offset;
+  LocationHash2D(double w, double h, double cell, Point off) : width(w), height(h), cell_size(cell), offset(off) {}
+};
+
+// highlevel_planners.rs:8-16.  Override get_desired_velocity for a host planner (batched
+// callback, slow path), or use the data planners below, which the device evaluates.
+struct HighLevelPlanner {
+  virtual ~HighLevelPlanner() = default;
+  virtual bool get_desired_velocity(const Agent&, std::chrono::duration<double>, Vec2f*) { return false; }
+  virtual void set_target(const Agent&, Point, Vec2f) {}
+  virtual void remove_agent_id(AgentId) {}
+  virtual cs_hlp_desc describe() {
+    cs_hlp_desc d{};
+    d.kind = CS_HLP_CALLBACK;
+    d.user = this;
+    d.velocity = [](void* u, size_t n, const uint64_t* ids, const double* pos, const double* vel, double t,
+                    double* out, uint8_t* some) {
+      auto* self = static_cast<HighLevelPlanner*>(u);
+      for (size_t i = 0; i < n; ++i) {
+        Agent a;
+        a.agent_id = ids[i];
+        a.position = {pos[2 * i], pos[2 * i + 1]};
+        a.velocity = {vel[2 * i], vel[2 * i + 1]};
+        Vec2f v;
+        some[i] = self->get_desired_velocity(a, std::chrono::duration<double>(t), &v) ? 1 : 0;
+        out[2 * i] = v.x;
+        out[2 * i + 1] = v.y;
+      }
+    };
+    d.set_target = [](void* u, uint64_t id, double px, double py, double tx, double ty, double ox, double oy) {
+      Agent a;
+      a.agent_id = id;
+      a.position = {px, py};
+      static_cast<HighLevelPlanner*>(u)->set_target(a, {tx, ty}, {ox, oy});
+    };
+    d.remove_agent = [](void* u, uint64_t id) { static_cast<HighLevelPlanner*>(u)->remove_agent_id(id); };
+    return d;
+  }
+};
+struct StubHighLevelPlan : HighLevelPlanner {  // lib.rs:391-420: Some(default_vel)
+  Vec2f default_vel;
+  explicit StubHighLevelPlan(Vec2f v) : default_vel(v) {}
+  cs_hlp_desc describe() override {
+    cs_hlp_desc d{};
+    d.kind = CS_HLP_CONSTANT;
+    d.vx = default_vel.x;
+    d.vy = default_vel.y;
+    return d;
+  }
+};
+struct IdParityHighLevelPlan : StubHighLevelPlan {  // rmf_crowdsim_viz/src/main.rs:20-30
+  using StubHighLevelPlan::StubHighLevelPlan;
+  cs_hlp_desc describe() override {
+    cs_hlp_desc d = StubHighLevelPlan::describe();
+    d.kind = CS_HLP_ID_PARITY;
+    return d;
+  }
+};
+
+struct LocalPlanner {  // local_planner.rs:7-18: only the shipped planners run on the device
+  virtual ~LocalPlanner() = default;
+  virtual uint32_t register_with(cs_engine*) = 0;
+};
+struct NoLocalPlan : LocalPlanner {  // no_local_plan.rs:7-18
+  uint32_t register_with(cs_engine* e) override { return cs_register_no_local_plan(e); }
+};
+struct Zanlungo : LocalPlanner {  // zanlungo.rs:31-48
+  cs_zanlungo_params p;
+  Zanlungo(double agent_scale, double obstacle_scale, double reaction_time, double force_distance,
+           double agent_mass, double agent_radius)
+      : p{agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass, agent_radius} {}
+  uint32_t register_with(cs_engine* e) override { return cs_register_zanlungo(e, &p); }
+};
+
+struct CrowdGenerator {  // source_sink.rs:30-33
+  virtual ~CrowdGenerator() = default;
+  virtual std::size_t get_number_to_spawn(std::chrono::duration<double> time_elapsed) const = 0;
+  virtual void fill(cs_source_sink_desc* d) const {
+    d->generator_kind = CS_GEN_CALLBACK;
+    d->generator_user = const_cast<CrowdGenerator*>(this);
+    d->generator = [](void* u, double dt) {
+      return static_cast<const CrowdGenerator*>(u)->get_number_to_spawn(std::chrono::duration<double>(dt));
+    };
+  }
+};
+struct MonotonicCrowd : CrowdGenerator {  // source_sink.rs:85-101
+  double rate;
+  explicit MonotonicCrowd(double r) : rate(r) {}
+  std::size_t get_number_to_spawn(std::chrono::duration<double> t) const override {
+    double v = t.count() * rate;
+    v = v < 0 ? 0 : (double)(long long)(v + 0.5);
+    return (std::size_t)v;
+  }
+  void fill(cs_source_sink_desc* d) const override {
+    d->generator_kind = CS_GEN_MONOTONIC;
+    d->rate = rate;
+  }
+};
+
+struct SourceSink {  // source_sink.rs:36-60
+  Vec2f source;
+  double radius_sink;
+  std::shared_ptr<CrowdGenerator> crowd_generator;
+  std::shared_ptr<HighLevelPlanner> high_level_planner;
+  std::shared_ptr<LocalPlanner> local_planner;
+  std::vector<Vec2f> waypoints;
+  bool loop_forever;
+  double agent_eyesight_range;
+};
+
+class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
+ public:
+  std::unordered_map<AgentId, Agent> agents;  // lib.rs:71, refreshed after every mutating call
+
+  explicit Simulation(const LocationHash2D& index, int device = 0) {  // lib.rs:103
+    cs_grid_desc g{index.width, index.height, index.cell_size, index.offset.x, index.offset.y};
+    cs_device_cfg cfg{};
+    cfg.device_ordinal = device;
+    engine_ = cs_create(&g, &cfg);
+    if (!engine_) throw std::runtime_error("cs_create failed: no HIP device (the engine has no CPU path)");
+  }
+  ~Simulation() { cs_destroy(engine_); }
+  Simulation(const Simulation&) = delete;
+  Simulation& operator=(const Simulation&) = delete;
+
+  std::vector<AgentId> add_agents(const std::vector<Point>& spawn_positions,  // lib.rs:119-156
+                                  std::shared_ptr<HighLevelPlanner> hlp, std::shared_ptr<LocalPlanner> lp,
+                                  double agent_eyesight_range) {
+    std::vector<double> xy;
+    for (const Point& p : spawn_positions) {
+      xy.push_back(p.x);
+      xy.push_back(p.y);
+    }
+    std::vector<uint64_t> ids(spawn_positions.size());
+    int rc = cs_add_agents(engine_, xy.data(), ids.size(), handle(hlp), handle(lp), agent_eyesight_range,
+                           ids.data());
+    after_mutation();
+    if (rc != 0) throw std::runtime_error(cs_last_error(engine_));
+    return std::vector<AgentId>(ids.begin(), ids.end());
+  }
+  std::size_t add_source_sink(std::shared_ptr<SourceSink> s) {  // lib.rs:159-161
+    cs_source_sink_desc d{};
+    d.source_x = s->source.x;
+    d.source_y = s->source.y;
+    d.radius_sink = s->radius_sink;
+    s->crowd_generator->fill(&d);
+    d.hlp = handle(s->high_level_planner);
+    d.lp = handle(s->local_planner);
+    std::vector<double> wps;
+    for (const Vec2f& w : s->waypoints) {
+      wps.push_back(w.x);
+      wps.push_back(w.y);
+    }
+    d.waypoints_xy = wps.data();
+    d.n_waypoints = s->waypoints.size();
+    d.loop_forever = s->loop_forever ? 1 : 0;
+    d.agent_eyesight_range = s->agent_eyesight_range;
+    sinks_.push_back(s);
+    return cs_add_source_sink(engine_, &d);
+  }
+  void remove_source_sink(std::size_t id) { cs_remove_source_sink(engine_, (uint32_t)id); }  // lib.rs:164
+  std::size_t add_event_listener(std::shared_ptr<EventListener> l) {                        // lib.rs:171
+    listeners_[next_listener_] = std::move(l);
+    return next_listener_++;
+  }
+  void remove_agents(AgentId agent) {  // lib.rs:176-192 (unknown id throws instead of panicking)
+    int rc = cs_remove_agent(engine_, agent);
+    after_mutation();
+    if (rc != 0) throw std::runtime_error(cs_last_error(engine_));
+  }
+  void step(std::chrono::duration<double> dur) {  // lib.rs:195-383
+    cs_step_report rep;
+    int rc = cs_step(engine_, dur.count(), &rep);
+    after_mutation();
+    if (rc != 0) throw std::runtime_error(cs_last_error(engine_));
+  }
+
+ private:
+  template <class P>
+  uint32_t handle(const std::shared_ptr<P>& p) {
+    auto it = handles_.find(p.get());
+    if (it != handles_.end()) return it->second;
+    uint32_t h = register_planner(p.get());
+    handles_[p.get()] = h;
+    keep_.push_back(p);
+    return h;
+  }
+  uint32_t register_planner(HighLevelPlanner* p) {
+    cs_hlp_desc d = p->describe();
+    return cs_register_hlp(engine_, &d);
+  }
+  uint32_t register_planner(LocalPlanner* p) { return p->register_with(engine_); }
+
+  void after_mutation() {
+    cs_event ev[256];
+    for (;;) {
+      std::size_t n = cs_drain_events(engine_, ev, 256);
+      for (std::size_t i = 0; i < n; ++i)
+        for (auto& kv : listeners_) {
+          if (ev[i].kind == CS_EVENT_SPAWNED) kv.second->agent_spawned({ev[i].x, ev[i].y}, ev[i].id);
+          if (ev[i].kind == CS_EVENT_DESTROYED) kv.second->agent_destroyed(ev[i].id);
+        }
+      if (n < 256) break;
+    }
+    std::vector<cs_agent_view> v(cs_agent_count(engine_));
+    std::size_t got = cs_read_agents(engine_, v.data(), v.size());
+    agents.clear();
+    for (std::size_t i = 0; i < got; ++i) {
+      Agent a;
+      a.agent_id = v[i].id;
+      a.position = {v[i].x, v[i].y};
+      a.velocity = {v[i].vx, v[i].vy};
+      a.next_waypoint = v[i].next_waypoint;
+      a.eyesight_range = v[i].eyesight_range;
+      agents[a.agent_id] = a;
+    }
+  }
+
+  cs_engine* engine_ = nullptr;
+  std::map<const void*, uint32_t> handles_;
+  std::vector<std::shared_ptr<void>> keep_;
+  std::vector<std::shared_ptr<SourceSink>> sinks_;
+  std::map<std::size_t, std::shared_ptr<EventListener>> listeners_;
+  std::size_t next_listener_ = 0;
+};
+
+}  // namespace rmf_crowdsim
+#endif

@@ -1,0 +1,99 @@
+// The reference's two step tests, restated over the C++ mirror (include/crowdsim.hpp):
+//   test_step_integration                 rmf_crowdsim/src/lib.rs:423-453
+//   test_event_listener_source_sink_api   rmf_crowdsim/tests/event_listeners_test.rs:65-111
+// Runs on an MI355X (tests/test_gpu_cpp_api.py builds and launches it).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "crowdsim.hpp"
+
+using namespace rmf_crowdsim;
+
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+      std::exit(1);                                                      \
+    }                                                                    \
+  } while (0)
+
+struct MockEventListener : EventListener {
+  std::vector<AgentId> added, removed;
+  void agent_spawned(Vec2f, AgentId agent) override { added.push_back(agent); }
+  void agent_destroyed(AgentId agent) override { removed.push_back(agent); }
+};
+
+static void test_step_integration() {
+  Vec2f velocity{1.0, 0.0};
+  auto step_size = std::chrono::duration<double>(1.0);
+  Simulation crowd_simulation(LocationHash2D(1000.0, 1000.0, 20.0, Point{-500.0, -500.0}));
+  CHECK(crowd_simulation.agents.size() == 0);
+  auto agents = crowd_simulation.add_agents({Point{0.0, 0.0}}, std::make_shared<StubHighLevelPlan>(velocity),
+                                            std::make_shared<NoLocalPlan>(), 100.0);
+  CHECK(agents.size() == 1);
+  CHECK(crowd_simulation.agents.size() == 1);
+  crowd_simulation.step(step_size);
+  CHECK(crowd_simulation.agents.size() == 1);
+  const Agent& a = crowd_simulation.agents.at(0);
+  CHECK(std::hypot(a.position.x - velocity.x, a.position.y - velocity.y) < 1e-5);
+}
+
+static void test_event_listener_source_sink_api() {
+  auto step_size = std::chrono::duration<double>(1.0);
+  Simulation crowd_simulation(LocationHash2D(1000.0, 1000.0, 20.0, Point{-500.0, -500.0}));
+  auto source_sink = std::make_shared<SourceSink>();
+  source_sink->source = {0.0, 0.0};
+  source_sink->waypoints = {Vec2f{20.0, 0.0}};
+  source_sink->radius_sink = 1.0;
+  source_sink->crowd_generator = std::make_shared<MonotonicCrowd>(1.0);
+  source_sink->high_level_planner = std::make_shared<StubHighLevelPlan>(Vec2f{1.0, 0.0});
+  source_sink->local_planner = std::make_shared<NoLocalPlan>();
+  source_sink->agent_eyesight_range = 5.0;
+  source_sink->loop_forever = false;
+  auto event_listener = std::make_shared<MockEventListener>();
+  crowd_simulation.add_event_listener(event_listener);
+  crowd_simulation.add_source_sink(source_sink);
+  for (std::size_t steps = 0; steps < 20; ++steps) {
+    CHECK(crowd_simulation.agents.size() == steps);
+    CHECK(event_listener->added.size() == steps);
+    crowd_simulation.step(step_size);
+  }
+  for (std::size_t steps = 20; steps < 40; ++steps) {
+    CHECK(crowd_simulation.agents.size() == 20);
+    CHECK(event_listener->added.size() == steps);
+    CHECK(event_listener->removed.size() == steps - 20);
+    crowd_simulation.step(step_size);
+  }
+}
+
+static void test_index_out_of_bounds_is_an_error() {
+  Simulation sim(LocationHash2D(2.0, 2.0, 1.0, Point{0.0, 0.0}));
+  bool threw = false;
+  try {
+    sim.add_agents({Point{5.0, 0.5}}, std::make_shared<StubHighLevelPlan>(Vec2f{0, 0}),
+                   std::make_shared<NoLocalPlan>(), 1.0);
+  } catch (const std::runtime_error& e) {
+    threw = std::string(e.what()) == "Index out of bounds";
+  }
+  CHECK(threw);
+}
+
+static void test_viz_scene() {  // rmf_crowdsim_viz/src/main.rs:64-94
+  Simulation sim(LocationHash2D(1000.0, 1000.0, 20.0, Point{-500.0, -500.0}));
+  sim.add_agents({Point{100, 100}, Point{100, -100}, Point{60, 100}},
+                 std::make_shared<IdParityHighLevelPlan>(Vec2f{0.0, 10.0}),
+                 std::make_shared<Zanlungo>(1.0, 1.0, 0.0, 40.0, 2.0, 20.0), 100.0);
+  for (int k = 0; k < 300; ++k) sim.step(std::chrono::duration<double>(0.05));
+  CHECK(std::fabs(sim.agents.at(0).position.x - 100.0) > 5.0);  // agent 0 dodged agent 1
+  CHECK(std::isfinite(sim.agents.at(1).position.y));
+}
+
+int main() {
+  test_step_integration();
+  test_event_listener_source_sink_api();
+  test_index_out_of_bounds_is_an_error();
+  test_viz_scene();
+  std::printf("4 passed\n");
+  return 0;
+}
