@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
     }
     cell_start[ncells] = total;
     ctr->n_alive = total;
-    ctr->n_owned = total;
+    ctr->n_owned = 0;  // the block builder that follows counts the owned agents
     ctr->n_destroyed = 0;  // the step kernel that follows counts into these
     ctr->n_waypoint_hits = 0;
     ctr->n_tti_zero = 0;
@@ -802,8 +802,11 @@ __global__ void __launch_bounds__(256) k_step_gather(StepParams P, AgentArrays i
 #define TILE_THREADS 256  // agents (= threads) per workgroup of the tiled neighbour kernel
 #endif
 
+// A workgroup of the tiled kernel owns `nrows` consecutive grid rows x the cells [y0, y1].
+// count != 0: a strip of one row cut at AGENT granularity (first, count <= TILE_THREADS).
+// count == 0: a band window of nrows rows cut at CELL granularity (agents = the cells' members).
 struct BlockDesc {
-  uint32_t row, first, count;
+  uint32_t row0, nrows, y0, y1, first, count;
 };
 
 __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t* __restrict__ cell_start,
@@ -838,7 +841,9 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
     for (uint32_t k = 0; k < nb; ++k) {
       if (excl + k < desc_cap) {
         BlockDesc d;
-        d.row = R;
+        d.row0 = R;
+        d.nrows = 1;
+        d.y0 = d.y1 = 0;
         d.first = first + k * TILE_THREADS;
         d.count = min((uint32_t)TILE_THREADS, cnt - k * TILE_THREADS);
         desc[excl + k] = d;
@@ -856,7 +861,87 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
   }
 }
 
-#define TILE_MAX_ROWS 17  // 2 * 8 + 1: eyesight up to 8 cells
+// Band windows: one workgroup of this builder per band of `rb` owned rows.  The inclusive
+// prefix of the per-column agent counts goes to `prefix`; window w takes the columns whose
+// first agent has band index in [w*target, (w+1)*target).  *n_blocks must be 0 on entry.
+__global__ void __launch_bounds__(256) k_build_bands(GridDev g, const uint32_t* __restrict__ cell_start,
+                                                     uint32_t rb, uint32_t target,
+                                                     uint32_t* __restrict__ prefix,
+                                                     BlockDesc* __restrict__ desc, uint32_t desc_cap,
+                                                     uint32_t* __restrict__ n_blocks,
+                                                     Counters* __restrict__ ctr) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t s_carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t row0 = g.own_x0 + blockIdx.x * rb;
+  const uint32_t nown = min(rb, g.own_x1 - row0);
+  const uint32_t ncols = g.own_y1 - g.own_y0;
+  uint32_t* __restrict__ incl = prefix + (unsigned long long)blockIdx.x * ncols;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < ncols; base += blockDim.x) {
+    const uint32_t y = base + threadIdx.x;
+    uint32_t c = 0;
+    if (y < ncols)
+      for (uint32_t r = 0; r < nown; ++r) {
+        const unsigned long long q = (unsigned long long)(row0 + r) * g.nx + g.own_y0 + y;
+        c += cell_start[q + 1] - cell_start[q];
+      }
+    const uint32_t w = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = w;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; ++k) woff += wsum[k];
+    if (y < ncols) incl[y] = s_carry + woff + w;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_carry += woff + w;
+    __syncthreads();
+  }
+  const uint32_t total = s_carry;
+  if (threadIdx.x == 0) {
+    if (total) atomicAdd(&ctr->n_owned, total);
+    if (blockIdx.x == 0) ctr->n_pending = cell_start[g.ncells];
+  }
+  // smallest y with incl[y] >= v (ncols if none); incl is non-decreasing
+  auto lb = [&](uint32_t v) {
+    uint32_t lo = 0, hi = ncols;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (incl[mid] >= v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  const uint32_t nw = (total + target - 1u) / target;
+  for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+    const uint32_t lo = w * target, hi = lo + target;
+    // first column whose first agent has band index >= lo (excl(y) = incl[y-1])
+    const uint32_t a = lo == 0 ? 0u : lb(lo) + 1u;
+    if (a >= ncols) continue;
+    const uint32_t ea = a == 0 ? 0u : incl[a - 1];
+    const uint32_t y0 = lb(ea + 1u);  // skip empty columns
+    if (y0 >= ncols) continue;
+    const uint32_t e0 = y0 == 0 ? 0u : incl[y0 - 1];
+    if (e0 >= hi) continue;  // a single column jumped over this window
+    // last column whose first agent has band index < hi
+    const uint32_t b = lb(hi);  // columns > b have excl >= hi
+    const uint32_t ylast = min(b, ncols - 1u);
+    const uint32_t y1 = lb(incl[ylast]);  // drop trailing empty columns
+    const uint32_t k = atomicAdd(n_blocks, 1u);
+    if (k < desc_cap) {
+      BlockDesc d;
+      d.row0 = row0;
+      d.nrows = nown;
+      d.y0 = g.own_y0 + y0;
+      d.y1 = g.own_y0 + y1;
+      d.first = 0;
+      d.count = 0;
+      desc[k] = d;
+    }
+  }
+}
+
+#define TILE_MAX_ROWS 24  // owned rows (<= 8) + 2 * 8 ghost rows: eyesight up to 8 cells
+#define TILE_MAX_OWN_ROWS 8
 
 struct TileCfg {
   int h;                // ceil(max eyesight / cell)
@@ -931,20 +1016,41 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   unsigned short* __restrict__ s_tab =
       reinterpret_cast<unsigned short*>(s_list + cfg.list_cap * TILE_THREADS);
 
-  // ---- geometry of the strip and its halo ----
+  // ---- geometry of the owned rows x cells and their halo ----
+  __shared__ uint32_t s_rfirst[TILE_MAX_OWN_ROWS], s_rpref[TILE_MAX_OWN_ROWS + 1];
   const int n_rows = (int)(g.ncells / g.nx);
-  const int R = (int)d.row;
-  const uint32_t c_lo = in.cell[d.first], c_hi = in.cell[d.first + d.count - 1];
-  const int ylo = (int)(c_lo - (uint32_t)R * g.nx), yhi = (int)(c_hi - (uint32_t)R * g.nx);
+  const int row0 = (int)d.row0, nown = (int)d.nrows;
+  const bool strip = d.count != 0;  // cut at agent granularity (k_build_blocks), else a band window
+  int ylo, yhi;
+  if (strip) {
+    const uint32_t c_lo = in.cell[d.first], c_hi = in.cell[d.first + d.count - 1];
+    ylo = (int)(c_lo - (uint32_t)row0 * g.nx);
+    yhi = (int)(c_hi - (uint32_t)row0 * g.nx);
+  } else {
+    ylo = (int)d.y0;
+    yhi = (int)d.y1;
+  }
   const int sy0 = max(ylo - cfg.h, 0), sy1 = min(yhi + cfg.h, (int)g.nx - 1);
   const int W1 = sy1 - sy0 + 2;
-  const int r0 = max(R - cfg.h, 0), r1 = min(R + cfg.h, n_rows - 1);
+  const int r0 = max(row0 - cfg.h, 0), r1 = min(row0 + nown - 1 + cfg.h, n_rows - 1);
   const int nr = r1 - r0 + 1;
   if (tid < nr) {
     unsigned long long rowbase = (unsigned long long)(r0 + tid) * g.nx;
     uint32_t g0 = cell_start[rowbase + sy0], g1 = cell_start[rowbase + sy1 + 1];
     s_g0[tid] = g0;
     s_base[tid + 1] = g1 - g0;
+  }
+  if (tid >= 64 && tid < 64 + nown) {  // the owned agents of each owned row (another wave)
+    const int r = tid - 64;
+    if (strip) {
+      s_rfirst[0] = d.first;
+      s_rpref[1] = d.count;
+    } else {
+      const unsigned long long rowbase = (unsigned long long)(row0 + r) * g.nx;
+      const uint32_t f = cell_start[rowbase + ylo];
+      s_rfirst[r] = f;
+      s_rpref[r + 1] = cell_start[rowbase + yhi + 1] - f;
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -955,9 +1061,17 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
       s_base[k + 1] = acc + c;
       acc += c;
     }
+    acc = 0;
+    s_rpref[0] = 0;
+    for (int k = 0; k < nown; ++k) {
+      uint32_t c = s_rpref[k + 1];
+      s_rpref[k + 1] = acc + c;
+      acc += c;
+    }
   }
   __syncthreads();
   const uint32_t S = s_base[nr];
+  const uint32_t n_own = s_rpref[nown];
   const bool tiled_ok = S <= cfg.agents_cap && S < (E16 ? 4096u : 65535u) &&
                         (uint32_t)(nr * W1) <= cfg.table_cap;
 
@@ -997,9 +1111,16 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
   }
   __syncthreads();
 
-  // ---- one thread = one agent; idle lanes of the last wave keep the wave-uniform loops ----
-  const bool active = tid < (int)d.count;
-  const uint32_t i = d.first + (active ? tid : 0);
+  // ---- one thread = one agent; idle lanes keep the wave-uniform loops going.  A window that
+  // holds more than TILE_THREADS agents (dense spots) is walked in chunks. ----
+  for (uint32_t chunk = 0; chunk < n_own; chunk += TILE_THREADS) {
+  const uint32_t a_idx = chunk + (uint32_t)tid;
+  const bool active = a_idx < n_own;
+  int own_r = 0;
+  if (active)
+    while (own_r + 1 < nown && a_idx >= s_rpref[own_r + 1]) ++own_r;
+  const int R = row0 + own_r;
+  const uint32_t i = active ? s_rfirst[own_r] + (a_idx - s_rpref[own_r]) : s_rfirst[0];
   const uint32_t cell = in.cell[i];
   Own o;
   o.gx = (uint32_t)R;
@@ -1134,9 +1255,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     // those with a larger id (used when the list had to be recycled).
     auto sweep = [&](bool FORCE) {
       for (int dx = -cfg.h; dx <= cfg.h; ++dx) {
-        const int rr = own_row + dx;  // staged row index, block-uniform
-        if (rr < 0 || rr >= nr) continue;
-        const bool x_in = dx >= lx && dx <= hx;
+        const int rr = own_row + dx;  // staged row index (per lane: lanes own different rows)
+        const bool x_in = dx >= lx && dx <= hx && rr >= 0 && rr < nr;
         const float oix = __builtin_fmaf(-(float)dx, g.cs, o.off.x);
         for (int dy = -cfg.h; dy <= cfg.h; ++dy) {
           const int cy = (int)o.gy + dy - sy0;
@@ -1227,6 +1347,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_step_tiled(
     }
   }
   if (active && !(cfg.debug & 4u)) step_epilogue(P, E, i, o.gx, o.gy, o.off, o.id, meta, grp, wx, wy);
+  }  // chunk
 }
 
 // ---------------------------------------------------------------------------
@@ -1503,9 +1624,12 @@ struct cs_engine {
   uint32_t blk_desc_cap = 0;
   uint32_t* n_blocks_dev = nullptr;
   double max_eyesight = 0.0;
-  uint32_t tile_blocks_per_cu = 3;  // LDS budget target of the tiled kernel (tuning knobs)
+  uint32_t tile_blocks_per_cu = 4;  // LDS budget target of the tiled kernel (tuning knobs)
   uint32_t tile_list_cap = 0;       // 0 = derive from the budget
   uint32_t tile_agents_slack = 0;
+  uint32_t tile_rows = 2;      // owned rows per workgroup (1 = strips cut at agent granularity)
+  uint32_t tile_target = 224;  // agents per band window
+  uint32_t* band_prefix = nullptr;
 
   // planners as data
   std::vector<cs_zanlungo_params> lp_params;
@@ -1591,7 +1715,7 @@ struct cs_engine {
     wp_events_cap = (uint32_t)ncap;
     HIP_OK(hipMalloc(&wp_events, (uint64_t)wp_events_cap * sizeof(uint2)));
     hipFree(blk_desc);
-    blk_desc_cap = (uint32_t)(ncap / TILE_THREADS + ncells / std::max<uint64_t>(nx, 1) + 8);
+    blk_desc_cap = (uint32_t)(ncap / 32 + ncells / std::max<uint64_t>(nx, 1) + 8);
     HIP_OK(hipMalloc(&blk_desc, (uint64_t)blk_desc_cap * sizeof(BlockDesc)));
     if (!n_blocks_dev) HIP_OK(hipMalloc(&n_blocks_dev, sizeof(uint32_t)));
     cap = ncap;
@@ -2067,7 +2191,12 @@ struct cs_engine {
       // LDS budget per workgroup: staged agents (20 B each, ~(2h+1) strips of 256 + halo ends),
       // the cell table and the per-thread neighbour lists; sized so that `tile_blocks_per_cu`
       // workgroups fit in the 160 KiB of a CU
-      cfg.agents_cap = std::min<uint32_t>(6144u, ((uint32_t)(2 * h + 1) * TILE_THREADS * 9u / 8u + 192u + tile_agents_slack + 63u) & ~63u);
+      const uint32_t rb = tile_rows;
+      if (rb <= 1)
+        cfg.agents_cap = ((uint32_t)(2 * h + 1) * TILE_THREADS * 9u / 8u + 192u + tile_agents_slack + 63u) & ~63u;
+      else
+        cfg.agents_cap = ((rb + 2u * h) * (tile_target / rb) * 5u / 4u + 192u + tile_agents_slack + 63u) & ~63u;
+      cfg.agents_cap = std::min<uint32_t>(6144u, cfg.agents_cap);
       cfg.table_cap = 1024u * (uint32_t)(h > 1 ? 2 : 1);
       const bool e16 = h <= 1 && cfg.agents_cap <= 4096u;
       const size_t entry = e16 ? 2u : 4u;
@@ -2083,10 +2212,20 @@ struct cs_engine {
       while ((size_t)cfg.list_cap * TILE_THREADS * entry < (size_t)cfg.agents_cap * 4u) cfg.list_cap += 8u;
       size_t lds = (size_t)cfg.agents_cap * 20u + (size_t)cfg.list_cap * TILE_THREADS * entry +
                    (size_t)cfg.table_cap * 2u;
-      hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
-                         blk_desc_cap, n_blocks_dev, ctr);
-      uint32_t grid_blocks = (n_slots + TILE_THREADS - 1u) / TILE_THREADS + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
-      grid_blocks = std::min(grid_blocks, blk_desc_cap);
+      uint32_t grid_blocks;
+      if (rb <= 1) {
+        hipLaunchKernelGGL(k_build_blocks, dim3(1), dim3(1024), 0, stream, gdev, cell_start, blk_desc,
+                           blk_desc_cap, n_blocks_dev, ctr);
+        grid_blocks = (n_slots + TILE_THREADS - 1u) / TILE_THREADS + (uint32_t)std::min<uint64_t>(n_rows, n_slots);
+      } else {
+        const uint32_t own_rows = gdev.own_x1 - gdev.own_x0;
+        const uint32_t n_bands = (own_rows + rb - 1u) / rb;
+        HIP_OK(hipMemsetAsync(n_blocks_dev, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_build_bands, dim3(n_bands), dim3(256), 0, stream, gdev, cell_start, rb,
+                           tile_target, band_prefix, blk_desc, blk_desc_cap, n_blocks_dev, ctr);
+        grid_blocks = n_slots / tile_target + n_bands + 1u;
+        grid_blocks = std::max(grid_blocks, (n_slots + TILE_THREADS - 1u) / TILE_THREADS);
+      }
       prof_begin(CS_K_NEIGHBOUR_FORCE);
       if (n_slots)
       {
@@ -2278,7 +2417,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->blk_desc); hipFree(e->n_blocks_dev);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -2370,11 +2509,14 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
+  if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(TILE_THREADS, std::max(32, atoi(v)));
   bool ok = true;
   ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   e->n_scan_blocks = (uint32_t)std::max<uint64_t>(1, (e->ncells + SCAN_TILE - 1) / SCAN_TILE);
   ok = ok && hipMalloc(&e->block_totals, e->n_scan_blocks * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&e->band_prefix, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->ctr, sizeof(Counters)) == hipSuccess;
   ok = ok && hipHostMalloc(&e->ctr_host, sizeof(Counters)) == hipSuccess;
   if (ok) {
