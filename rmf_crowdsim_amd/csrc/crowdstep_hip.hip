@@ -367,7 +367,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
                                                            const uint32_t* __restrict__ block_totals,
                                                            uint32_t nblocks,
                                                            uint32_t* __restrict__ cell_start,
-                                                           Counters* __restrict__ ctr) {
+                                                           Counters* __restrict__ ctr,
+                                                           uint32_t* __restrict__ n_blocks) {
   __shared__ uint32_t wsum[SCAN_BLOCK / 64];
   __shared__ uint32_t s_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,6 +426,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(uint32_t* __restrict_
     cell_start[ncells] = total;
     ctr->n_alive = total;
     ctr->n_owned = 0;  // the block builder that follows counts the owned agents
+    *n_blocks = 0;     // ... and the workgroups of the step kernel
     ctr->n_destroyed = 0;  // the step kernel that follows counts into these
     ctr->n_waypoint_hits = 0;
     ctr->n_tti_zero = 0;
@@ -864,6 +866,7 @@ __global__ void __launch_bounds__(1024) k_build_blocks(GridDev g, const uint32_t
 // Band windows: one workgroup of this builder per band of `rb` owned rows.  The inclusive
 // prefix of the per-column agent counts goes to `prefix`; window w takes the columns whose
 // first agent has band index in [w*target, (w+1)*target).  *n_blocks must be 0 on entry.
+#define BAND_LDS_COLS 4096
 __global__ void __launch_bounds__(256) k_build_bands(GridDev g, const uint32_t* __restrict__ cell_start,
                                                      uint32_t rb, uint32_t target,
                                                      uint32_t* __restrict__ prefix,
@@ -876,7 +879,10 @@ __global__ void __launch_bounds__(256) k_build_bands(GridDev g, const uint32_t* 
   const uint32_t row0 = g.own_x0 + blockIdx.x * rb;
   const uint32_t nown = min(rb, g.own_x1 - row0);
   const uint32_t ncols = g.own_y1 - g.own_y0;
-  uint32_t* __restrict__ incl = prefix + (unsigned long long)blockIdx.x * ncols;
+  // the prefix lives in LDS when the band is narrow enough (binary searches below), else in HBM
+  __shared__ uint32_t s_incl[BAND_LDS_COLS];
+  uint32_t* __restrict__ incl =
+      ncols <= BAND_LDS_COLS ? s_incl : prefix + (unsigned long long)blockIdx.x * ncols;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   for (uint32_t base = 0; base < ncols; base += blockDim.x) {
@@ -1926,7 +1932,7 @@ struct cs_engine {
     hipLaunchKernelGGL(k_scan_totals, dim3(n_scan_blocks), dim3(SCAN_BLOCK), 0, stream, cell_count,
                        (uint32_t)ncells, block_totals);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(SCAN_BLOCK), 0, stream, cell_count,
-                       (uint32_t)ncells, block_totals, n_scan_blocks, cell_start, ctr);
+                       (uint32_t)ncells, block_totals, n_scan_blocks, cell_start, ctr, n_blocks_dev);
     prof_end();
     prof_begin(CS_K_SCATTER);
     if (n_slots)
@@ -2141,7 +2147,8 @@ struct cs_engine {
     }
 
     // ---- index for this step (location_hash_2d.rs:126-149) ----
-    if (sorted)  // no re-sort this step: the scan is what normally zeroes the step counters
+    const bool rebuilt = !sorted;
+    if (!rebuilt)  // no re-sort this step: the scan is what normally zeroes the step counters
       HIP_OK(hipMemsetAsync(&ctr->n_destroyed, 0, 6 * sizeof(uint32_t), stream));
     if (int rc = rebuild()) return rc;
 
@@ -2220,7 +2227,7 @@ struct cs_engine {
       } else {
         const uint32_t own_rows = gdev.own_x1 - gdev.own_x0;
         const uint32_t n_bands = (own_rows + rb - 1u) / rb;
-        HIP_OK(hipMemsetAsync(n_blocks_dev, 0, sizeof(uint32_t), stream));
+        if (!rebuilt) HIP_OK(hipMemsetAsync(n_blocks_dev, 0, sizeof(uint32_t), stream));  // else the scan did
         hipLaunchKernelGGL(k_build_bands, dim3(n_bands), dim3(256), 0, stream, gdev, cell_start, rb,
                            tile_target, band_prefix, blk_desc, blk_desc_cap, n_blocks_dev, ctr);
         grid_blocks = n_slots / tile_target + n_bands + 1u;
