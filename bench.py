@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--cell", type=float, default=2.0)
     ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
     ap.add_argument("--kernel", choices=["auto", "tiled", "gather"], default="auto")
+    ap.add_argument("--workload", choices=["uniform", "stream"], default="uniform",
+                    help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
     args = ap.parse_args()
@@ -101,7 +103,30 @@ def main():
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
     from rmf_crowdsim_amd.tiles import DistributedTiles, default_tiling
     lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
-    if world == 1:
+    n_sinks = 0
+    if args.workload == "stream":
+        # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
+        # step runs the spawn kernel, the sink test and the compaction in the re-sort
+        if world != 1:
+            raise SystemExit("source-sinks are single-GPU for now (DESIGN.md section 7)")
+        from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
+        tiling = (1, 1)
+        lanes, grid, fill_steps = scenes.stream_lanes(args.agents, cell_size=args.cell)
+        extent = grid["width"]
+        sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
+                         stream=torch.cuda.current_stream().cuda_stream,
+                         capacity_hint=int(args.agents * 1.2) + 4096)
+        plans = {}
+        for src, dst, vel in lanes:
+            hlp = plans.setdefault(vel, StubHighLevelPlan(vel))
+            sim.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False,
+                                           args.eyesight))
+        n_sinks = len(lanes)
+        stepper = sim
+        for _ in range(fill_steps):
+            sim.step(0.05, report=False)
+        speed = scenes.WALK_SPEED
+    elif world == 1:
         tiling = (1, 1)
         pts, grid, extent, group = scenes.uniform_crowd(args.agents, seed=7, cell_size=args.cell)
         sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
@@ -118,8 +143,9 @@ def main():
                                    density_per_cell=1.5 * scenes.METRIC_DENSITY * args.cell ** 2,
                                    capacity_hint=int(args.agents * 1.1) + 4096, flags=flags)
         sim = stepper.sim
-    scenes.add_counterflow(stepper, pts, group, speed, lp, args.eyesight)
-    del pts, group
+    if args.workload == "uniform":
+        scenes.add_counterflow(stepper, pts, group, speed, lp, args.eyesight)
+        del pts, group
 
     def sync_all():
         torch.cuda.synchronize()
@@ -150,11 +176,13 @@ def main():
 
     # the scene must still be the scene: everyone alive and finite
     if args.debug:
-        rep = {"n_tti_zero": -1, "n_nonfinite": -1, "n_agents": -1}
+        rep = {"n_tti_zero": -1, "n_nonfinite": -1, "n_agents": args.agents}
     else:
         stepper.step(0.05, report=True)
         rep = sim.last_report
     total_agents = args.agents * world
+    if args.workload == "stream":
+        total_agents = rep["n_agents"]  # what the sinks actually sustain
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
     ncells = int(round(grid["width"] / grid["cell_size"])) ** 2 // world  # per tile
@@ -168,7 +196,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01", "k4_traffic.json")) as f:
             tr = json.load(f)
         if (tr["agents"], tr["cell"], tr["eyesight"]) == (args.agents, args.cell, args.eyesight) \
-                and args.kernel != "gather" and not args.debug:
+                and args.kernel != "gather" and not args.debug and args.workload == "uniform" and world == 1:
             traffic = tr["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -188,9 +216,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.agents} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered "
-                            f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
-                            f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s",
+                "workload": (f"{args.agents} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered "
+                             f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
+                             f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s")
+                if args.workload == "uniform" else
+                (f"~{args.agents} agents sustained by {n_sinks} source-sinks (MonotonicCrowd, 16 m lanes 1 m "
+                 f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
+                 f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
+                "n_spawned_last_step": rep.get("n_spawned"), "n_destroyed_last_step": rep.get("n_destroyed"),
                 "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
                 "speed": speed, "kernel": args.kernel,
                 "parallelism": "1 GPU" if world == 1 else

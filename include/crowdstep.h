@@ -211,6 +211,9 @@ size_t cs_agent_count(cs_engine*);                       /* agents.len(), lib.rs
 /* `pub agents` view, ascending id; returns number written       lib.rs:71    */
 size_t cs_read_agents(cs_engine*, cs_agent_view* out, size_t cap);
 size_t cs_drain_events(cs_engine*, cs_event* out, size_t cap);
+/* Events are queued only while recording is on (default on).  A host without listeners
+ * (lib.rs:88 registry empty) turns it off so the queue cannot grow. */
+void cs_event_recording(cs_engine*, int on);
 /* SpatialIndex::get_neighbours_in_radius                location_hash_2d.rs:240-258
  * returns the full count; writes min(count, cap) ids in reference cell order
  * (x-major, y-minor) with ascending id inside a cell. */

@@ -519,6 +519,7 @@ struct cs_engine {
   std::vector<std::shared_ptr<HighLevelPlanner>> hlps;
   std::mutex planner_lock;  // stands in for the per-planner Mutex (lib.rs:264-268,288-291)
   std::vector<cs_event> events;
+  bool record_events = true;
   std::string error;
   bool gauss_seidel = false;
 
@@ -558,7 +559,7 @@ struct cs_engine {
       e.id = id;
       e.x = (double)p.x;
       e.y = (double)p.y;
-      events.push_back(e);
+      if (record_events) events.push_back(e);
     }
     return true;
   }
@@ -576,7 +577,7 @@ struct cs_engine {
     e.source_sink = UINT32_MAX;
     e.id = id;
     e.x = e.y = 0;
-    events.push_back(e);
+    if (record_events) events.push_back(e);
   }
 
   // lib.rs:195-383
@@ -830,6 +831,11 @@ size_t cs_drain_events(cs_engine* e, cs_event* out, size_t cap) {
   for (size_t i = 0; i < n; ++i) out[i] = e->events[i];
   e->events.erase(e->events.begin(), e->events.begin() + n);
   return n;
+}
+
+void cs_event_recording(cs_engine* e, int on) {
+  e->record_events = on != 0;
+  if (!on) e->events.clear();
 }
 
 size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids,

@@ -104,6 +104,7 @@ SYMBOLS = {
     "cs_agent_count": (C.c_size_t, [C.c_void_p]),
     "cs_read_agents": (C.c_size_t, [C.c_void_p, C.POINTER(AgentView), C.c_size_t]),
     "cs_drain_events": (C.c_size_t, [C.c_void_p, C.POINTER(Event), C.c_size_t]),
+    "cs_event_recording": (None, [C.c_void_p, C.c_int]),
     "cs_query_radius": (C.c_size_t, [C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.POINTER(C.c_uint64), C.c_size_t]),
     "cs_query_knn": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_double, C.c_double,

@@ -28,7 +28,7 @@
 #include "crowdstep.h"
 
 #define CS_INVALID_CELL 0xFFFFFFFFu
-#define CS_MAX_GROUPS 4096u
+#define CS_MAX_GROUPS 65535u  // the group index travels in 16 bits of `meta`
 #define CS_SPAWN_OCCUPANCY_RADIUS 0.4  // hard-coded in the reference, lib.rs:212-214
 
 // ---------------------------------------------------------------------------
@@ -154,8 +154,12 @@ __device__ __noinline__ float ttc_tiny_f32(float rvx, float rvy, float rpx, floa
 
 __device__ __forceinline__ float ttc_f32(float rvx, float rvy, float rpx, float rpy, float d2,
                                          float R2) {
-  if (__builtin_expect(fmaxf(fabsf(rvx), fabsf(rvy)) < 1e-12f, 0))
+  const float rvmax = fmaxf(fabsf(rvx), fabsf(rvy));
+  if (__builtin_expect(rvmax < 1e-12f, 0)) {
+    // equal velocities (a lane of walkers): a = b = 0, 0/0 = NaN fails every comparison -> inf
+    if (rvmax == 0.0f) return f_inf();
     return ttc_tiny_f32(rvx, rvy, rpx, rpy, d2, R2);
+  }
   const float a = __builtin_fmaf(rvx, rvx, rvy * rvy);  // >= 1e-24 here
   const float bh = __builtin_fmaf(rvx, rpx, rvy * rpy);
   const float c = d2 - R2;
@@ -1661,6 +1665,7 @@ struct cs_engine {
   uint64_t next_id = 0;  // last_alloc_agent_id, lib.rs:83
   uint64_t n_alive_host = 0;
   std::vector<cs_event> events;
+  bool record_events = true;
 
   // per-kernel hipEvent timing
   uint32_t profiling = 0;  // bitmask of CS_K_* kernels to time
@@ -2055,7 +2060,7 @@ struct cs_engine {
       ev.id = id;
       ev.x = xy[2 * k];
       ev.y = xy[2 * k + 1];
-      events.push_back(ev);
+      if (record_events) events.push_back(ev);
     }
     const size_t ok = ids.size();
     vel.assign(ok, make_float2(0.f, 0.f));
@@ -2319,7 +2324,7 @@ struct cs_engine {
       ev.id = first_id + k;
       ev.x = h.d.source_x;
       ev.y = h.d.source_y;
-      events.push_back(ev);
+      if (record_events) events.push_back(ev);
       const cs_hlp_desc& p = hlps[h.d.hlp];
       if (p.kind == CS_HLP_CALLBACK && p.set_target && !h.waypoints.empty())
         p.set_target(p.user, ev.id, ev.x, ev.y, h.waypoints[0], h.waypoints[1], h.d.radius_sink,
@@ -2358,7 +2363,7 @@ struct cs_engine {
         ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
         ev.id = it.x;
         ev.x = ev.y = 0;
-        events.push_back(ev);
+        if (record_events) events.push_back(ev);
       }
     }
     return 0;
@@ -2601,7 +2606,7 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
     ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
     ev.id = id;
     ev.x = ev.y = 0;
-    e->events.push_back(ev);
+    if (e->record_events) e->events.push_back(ev);
     return 0;
   }
   e->error = "unknown agent id";
@@ -2609,6 +2614,10 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
 }
 
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
+  if (e->groups.size() + 1 >= CS_MAX_GROUPS || d->n_waypoints == 0 || d->n_waypoints > 65535) {
+    e->error = "too many source-sinks / planner groups (65535) or bad waypoint count";
+    return UINT32_MAX;
+  }
   HostSink s;
   s.d = *d;
   s.waypoints.assign(d->waypoints_xy, d->waypoints_xy + 2 * d->n_waypoints);
@@ -2676,6 +2685,11 @@ size_t cs_drain_events(cs_engine* e, cs_event* out, size_t cap) {
   for (size_t i = 0; i < n; ++i) out[i] = e->events[i];
   e->events.erase(e->events.begin(), e->events.begin() + n);
   return n;
+}
+
+void cs_event_recording(cs_engine* e, int on) {
+  e->record_events = on != 0;
+  if (!on) e->events.clear();
 }
 
 // SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258

@@ -111,3 +111,31 @@ def add_counterflow(sim, pts, group, speed, local_planner, eyesight, axis=1):
     ids[group == 1] = sim.add_agents(pts[group == 1], StubHighLevelPlan(tuple(v)), local_planner,
                                      eyesight)
     return ids
+
+
+# ---- config 4: a crowd fed by source-sinks --------------------------------------------
+def stream_lanes(n_agents, lane_length=16.0, lane_gap=1.0, release_gap=0.4, cell_size=2.0, margin=10.0):
+    """Source-sink lanes whose steady state holds ~n_agents: parallel lanes `lane_gap` apart,
+    alternating direction, each `lane_length` long (an agent is released whenever the previous
+    one is `release_gap` = the reference's hard-coded 0.4 m away, lib.rs:212-217).
+    Returns (list of (source, waypoint, velocity), grid kwargs, steps to fill at 1.3 m/s, dt 0.05)."""
+    per_lane = lane_length / release_gap
+    n_lanes = int(math.ceil(n_agents / per_lane))
+    cols = int(math.ceil(math.sqrt(n_lanes * lane_length / lane_gap) / lane_length * lane_length / lane_gap))
+    cols = max(1, int(math.ceil(math.sqrt(n_lanes * lane_length * lane_gap) / lane_gap)))
+    rows = int(math.ceil(n_lanes / cols))
+    width = cols * lane_gap + 2 * margin
+    height = rows * (lane_length + 2.0) + 2 * margin
+    side = int(math.ceil(max(width, height) / cell_size)) * cell_size
+    lanes = []
+    for k in range(n_lanes):
+        c, r = k % cols, k // cols
+        x = margin + (c + 0.5) * lane_gap
+        y0 = margin + r * (lane_length + 2.0) + 1.0
+        if c % 2 == 0:
+            lanes.append(((x, y0), (x, y0 + lane_length), (0.0, WALK_SPEED)))
+        else:
+            lanes.append(((x, y0 + lane_length), (x, y0), (0.0, -WALK_SPEED)))
+    grid = dict(width=side, height=side, cell_size=cell_size, offset=(0.0, 0.0))
+    fill_steps = int(lane_length / (WALK_SPEED * 0.05)) + 20
+    return lanes, grid, fill_steps

@@ -264,6 +264,7 @@ class Simulation:
         self._engine = self._lib.cs_create(C.byref(grid), C.byref(cfg))
         if not self._engine:
             raise CrowdSimError("cs_create failed (no usable HIP device?)")
+        self._lib.cs_event_recording(self._engine, 0)  # no listeners yet (lib.rs:88)
         self._planner_handles = {}
         self._planners_alive = []
         self._listeners = {}
@@ -359,6 +360,7 @@ class Simulation:
         handle = self._next_listener
         self._next_listener += 1
         self._listeners[handle] = event_listener
+        self._lib.cs_event_recording(self._engine, 1)
         return handle
 
     def remove_agents(self, agent):
