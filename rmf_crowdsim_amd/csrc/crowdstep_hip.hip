@@ -1658,6 +1658,7 @@ struct cs_engine {
   uint32_t* src_sorted = nullptr;
   uint32_t* src_occupied = nullptr;
   uint32_t* want_dev = nullptr;
+  uint32_t* want_host = nullptr;  // pinned: the H2D copy of a step may still be in flight at return
   uint32_t* spawned_slots_dev = nullptr;
   bool sinks_dirty = true;
   uint32_t n_live_sinks = 0;
@@ -1886,7 +1887,8 @@ struct cs_engine {
       d.eyesight = (float)h.d.agent_eyesight_range;
     }
     hipFree(sinks_dev); hipFree(waypoints_dev); hipFree(src_sorted); hipFree(src_occupied);
-    hipFree(want_dev); hipFree(spawned_slots_dev);
+    hipFree(want_dev); hipFree(spawned_slots_dev); hipHostFree(want_host);
+    want_host = nullptr;
     sinks_dev = nullptr; waypoints_dev = nullptr; src_sorted = nullptr; src_occupied = nullptr;
     want_dev = nullptr; spawned_slots_dev = nullptr;
     size_t nalloc = std::max<size_t>(ns, 1);
@@ -1895,6 +1897,7 @@ struct cs_engine {
     HIP_OK(hipMalloc(&src_sorted, nalloc * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&src_occupied, nalloc * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&want_dev, nalloc * sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc(&want_host, nalloc * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&spawned_slots_dev, nalloc * sizeof(uint32_t)));
     HIP_OK(hipMemset(src_occupied, 0, nalloc * sizeof(uint32_t)));
     if (ns) HIP_OK(hipMemcpy(sinks_dev, sd.data(), ns * sizeof(SinkDev), hipMemcpyHostToDevice));
@@ -2107,9 +2110,10 @@ struct cs_engine {
     uint32_t n_want = 0;
     const uint64_t first_spawn_id = next_id;
     if (has_sinks) {
-      std::vector<uint32_t> want(sinks.size(), 0);
+      uint32_t* want = want_host;  // the previous step ended with a sync: its copy is done
       for (size_t s = 0; s < sinks.size(); ++s) {
         HostSink& h = sinks[s];
+        want[s] = 0;
         if (!h.alive) continue;
         uint64_t call = h.calls++;
         uint64_t nsp = 0;
@@ -2137,15 +2141,14 @@ struct cs_engine {
         if (int rc = reserve((uint64_t)n_slots + n_want)) return rc;
         if (int rc = mark_occupancy()) return rc;  // no-op right after a step
         if (int rc = recount()) return rc;         // no-op right after a step
-        HIP_OK(hipMemcpyAsync(want_dev, want.data(), want.size() * sizeof(uint32_t),
-                              hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(want_dev, want, sinks.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              stream));
         prof_begin(CS_K_SPAWN);
         hipLaunchKernelGGL(k_spawn, dim3(1), dim3(1024), 0, stream, buf[cur], n_slots, (uint32_t)cap,
                            sinks_dev, want_dev, (uint32_t)sinks.size(), n_want, src_occupied,
                            cell_count, (uint32_t)first_spawn_id, spawned_slots_dev, ctr);
         prof_end();
         HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(stream));  // `want` dies at scope exit
         n_slots += n_want;
         sorted = false;
       }
@@ -2314,6 +2317,10 @@ struct cs_engine {
   // in ascending sink order.
   int finish_spawn_events(uint32_t n_spawned, uint64_t first_id) {
     if (!n_spawned) return 0;
+    if (!record_events && !any_callback_hlp) {  // nobody listens: ids advance, nothing to read back
+      next_id = first_id + n_spawned;
+      return 0;
+    }
     std::vector<uint32_t> slots(n_spawned);
     HIP_OK(hipMemcpy(slots.data(), spawned_slots_dev, n_spawned * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < n_spawned; ++k) {
@@ -2349,7 +2356,7 @@ struct cs_engine {
         (void)ev;
       }
     }
-    if (c.n_destroyed) {
+    if (c.n_destroyed && (record_events || any_callback_hlp)) {
       uint32_t m = std::min(c.n_destroyed, destroyed_cap);
       std::vector<uint2> d(m);
       HIP_OK(hipMemcpy(d.data(), destroyed, m * sizeof(uint2), hipMemcpyDeviceToHost));
@@ -2429,7 +2436,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
