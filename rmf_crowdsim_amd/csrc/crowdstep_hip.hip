@@ -490,6 +490,12 @@ __device__ __forceinline__ uint32_t wave_histogram_rank(uint32_t* __restrict__ c
 // histogram for the next scatter, source-occupancy marks.
 // (lib.rs:295-346; commit lib.rs:350-359 is the write into the `out` arrays)
 // ---------------------------------------------------------------------------
+// set_target(&self.agents[&agent_id], waypoints[next], (r, r)): the agent as it was BEFORE the step
+struct WpEvent {
+  uint32_t id, group, next_wp, cell;
+  float ox, oy;
+};
+
 struct EpilogueCtx {
   AgentArrays out;
   uint32_t* cell_count;
@@ -500,7 +506,7 @@ struct EpilogueCtx {
   double grid_off_x, grid_off_y, cell_size;
   uint2* destroyed;  // append list of (id, meta)
   uint32_t destroyed_cap;
-  uint2* wp_events;  // (id, new next_waypoint) for host set_target callbacks
+  WpEvent* wp_events;  // waypoint advances of agents with a host planner (set_target, lib.rs:325-333)
   uint32_t wp_events_cap;
   // source occupancy for the next step's spawn phase
   const uint32_t* src_cell_start;  // per cell, into src_sorted
@@ -536,7 +542,7 @@ __device__ __forceinline__ void step_epilogue(const StepParams& P, const Epilogu
           next_wp += 1;
           if (grp.hlp_kind == CS_HLP_CALLBACK) {
             uint32_t k = atomicAdd(&E.ctr->n_wp_events, 1u);
-            if (k < E.wp_events_cap) E.wp_events[k] = make_uint2(id, next_wp);
+            if (k < E.wp_events_cap) E.wp_events[k] = WpEvent{id, meta & 0xFFFFu, next_wp, gx * P.g.nx + gy, off.x, off.y};
           }
         }
       }
@@ -1628,7 +1634,7 @@ struct cs_engine {
   Counters* ctr_host = nullptr;  // pinned
   uint2* destroyed = nullptr;
   uint32_t destroyed_cap = 0;
-  uint2* wp_events = nullptr;
+  WpEvent* wp_events = nullptr;
   uint32_t wp_events_cap = 0;
   BlockDesc* blk_desc = nullptr;  // work decomposition of the tiled neighbour kernel
   uint32_t blk_desc_cap = 0;
@@ -1725,7 +1731,7 @@ struct cs_engine {
     HIP_OK(hipMalloc(&destroyed, (uint64_t)destroyed_cap * sizeof(uint2)));
     hipFree(wp_events);
     wp_events_cap = (uint32_t)ncap;
-    HIP_OK(hipMalloc(&wp_events, (uint64_t)wp_events_cap * sizeof(uint2)));
+    HIP_OK(hipMalloc(&wp_events, (uint64_t)wp_events_cap * sizeof(WpEvent)));
     hipFree(blk_desc);
     blk_desc_cap = (uint32_t)(ncap / 32 + ncells / std::max<uint64_t>(nx, 1) + 8);
     HIP_OK(hipMalloc(&blk_desc, (uint64_t)blk_desc_cap * sizeof(BlockDesc)));
@@ -2108,6 +2114,7 @@ struct cs_engine {
 
     // ---- Phase A: spawn (lib.rs:199-254) ----
     uint32_t n_want = 0;
+    bool spawn_events_done = false;
     const uint64_t first_spawn_id = next_id;
     if (has_sinks) {
       uint32_t* want = want_host;  // the previous step ended with a sync: its copy is done
@@ -2151,6 +2158,14 @@ struct cs_engine {
         HIP_OK(hipGetLastError());
         n_slots += n_want;
         sorted = false;
+        if (any_callback_hlp) {
+          // a host planner must see set_target(new agent) BEFORE this step asks it for a velocity
+          // (lib.rs:236-250 runs before the update loop): read the spawn result back now
+          Counters c0;
+          if (int rc = read_counters(&c0)) return rc;
+          if (int rc = finish_spawn_events(c0.n_spawned, first_spawn_id)) return rc;
+          spawn_events_done = true;
+        }
       }
     }
 
@@ -2284,7 +2299,7 @@ struct cs_engine {
       occ_valid = false;
       n_alive_host = c.n_alive;
       n_slots = c.n_alive;
-      finish_spawn_events(c.n_spawned, first_spawn_id);
+      if (!spawn_events_done) finish_spawn_events(c.n_spawned, first_spawn_id);
       error = "Index out of bounds";
       return 1;
     }
@@ -2293,7 +2308,8 @@ struct cs_engine {
     hist_valid = true;
     occ_valid = has_sinks;
     n_slots = c.n_alive;  // the step wrote exactly the live population
-    if (int rc = finish_spawn_events(c.n_spawned, first_spawn_id)) return rc;
+    if (!spawn_events_done)
+      if (int rc = finish_spawn_events(c.n_spawned, first_spawn_id)) return rc;
     if (int rc = finish_destroy_events(c)) return rc;
     n_alive_host = tile ? (uint64_t)c.n_owned : (uint64_t)c.n_alive - c.n_destroyed;
     if (c.n_halo_overflow) {
@@ -2346,14 +2362,19 @@ struct cs_engine {
   int finish_destroy_events(const Counters& c) {
     if (c.n_wp_events) {
       uint32_t m = std::min(c.n_wp_events, wp_events_cap);
-      std::vector<uint2> w(m);
-      HIP_OK(hipMemcpy(w.data(), wp_events, m * sizeof(uint2), hipMemcpyDeviceToHost));
-      std::sort(w.begin(), w.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
-      // the callback wants the agent's position: the OLD one (lib.rs:330); the host
-      // planner receives the id and the new target, position is not tracked here.
-      for (auto& ev : w) {
-        // group lookup needs the agent's meta; wp events are only emitted for callback planners
-        (void)ev;
+      std::vector<WpEvent> w(m);
+      HIP_OK(hipMemcpy(w.data(), wp_events, m * sizeof(WpEvent), hipMemcpyDeviceToHost));
+      std::sort(w.begin(), w.end(), [](const WpEvent& a, const WpEvent& b) { return a.id < b.id; });
+      for (const WpEvent& ev : w) {  // ascending id = the canonical visiting order
+        const HostGroup& g = groups[ev.group];
+        const cs_hlp_desc& p = hlps[g.hlp];
+        if (p.kind != CS_HLP_CALLBACK || !p.set_target || g.sink < 0) continue;
+        const HostSink& h = sinks[g.sink];
+        if (2 * (size_t)ev.next_wp + 1 >= h.waypoints.size()) continue;
+        double px, py;
+        to_global(ev.cell, ev.ox, ev.oy, &px, &py);
+        p.set_target(p.user, ev.id, px, py, h.waypoints[2 * ev.next_wp], h.waypoints[2 * ev.next_wp + 1],
+                     h.d.radius_sink, h.d.radius_sink);
       }
     }
     if (c.n_destroyed && (record_events || any_callback_hlp)) {

@@ -378,3 +378,46 @@ def test_dense_hotspots_take_the_overflow_paths(flags):
           f"{float(np.quantile(rel, 0.999)):.2e} max {float(rel.max()):.2e}")
     assert max_rel_err(a, b, extent) <= 1e-4
     assert np.quantile(rel, 0.999) <= 2e-3 and (rel > 2e-3).sum() <= len(a) // 1000
+
+
+# ---- host planner on a source-sink route: set_target / remove_agent_id callbacks -----------
+class RoutePlan(HighLevelPlanner):
+    """Walks towards the last target it was given (what RMFPlanner does with its route cache)."""
+
+    def __init__(self):
+        self.targets, self.log = {}, []
+
+    def get_desired_velocity(self, agent, time):
+        t = self.targets.get(agent.agent_id)
+        if t is None:
+            return None
+        d = t - agent.position
+        return tuple(1.3 * d / max(np.linalg.norm(d), 1e-9))
+
+    def set_target(self, agent, point, tolerance):
+        self.targets[agent.agent_id] = np.array(point)
+        self.log.append(("set", agent.agent_id, round(float(agent.position[0]), 3), tuple(point), tuple(tolerance)))
+
+    def remove_agent_id(self, agent_id):
+        self.targets.pop(agent_id, None)
+        self.log.append(("remove", agent_id))
+
+
+def test_callback_planner_gets_set_target_and_remove():
+    logs, finals = [], []
+    for cls in (Simulation, OracleSimulation):
+        sim = cls(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)))
+        plan = RoutePlan()
+        sim.add_source_sink(SourceSink((10.0, 50.0), 0.5, MonotonicCrowd(10.0), plan, NoLocalPlan(),
+                                       [(14.0, 50.0), (14.0, 54.0), (18.0, 54.0)], False, 2.0))
+        for _ in range(260):
+            sim.step(0.05)
+        logs.append(plan.log)
+        finals.append(sim.read_agents())
+    assert len(logs[0]) > 40 and any(e[0] == "remove" for e in logs[0])
+    assert [e[:2] for e in logs[0]] == [e[:2] for e in logs[1]]          # same calls, same order
+    for a, b in zip(logs[0], logs[1]):
+        if a[0] == "set":
+            assert a[3] == b[3] and a[4] == b[4] and abs(a[2] - b[2]) < 1e-3
+    assert (finals[0]["id"] == finals[1]["id"]).all()
+    assert np.abs(finals[0]["x"] - finals[1]["x"]).max() < 1e-3
