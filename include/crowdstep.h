@@ -259,6 +259,17 @@ int cs_halo_set_buffers(cs_engine*, uint32_t dir, void* send_dev, void* recv_dev
 int cs_halo_pack(cs_engine*, uint32_t axis);
 /* Merge what arrived on one axis into the tile (as owned agents or ghosts, by cell). */
 int cs_halo_unpack(cs_engine*, uint32_t axis);
+/* Source-sinks on tiles: every tile registers ALL source-sinks (same order); agent ids must
+ * follow the global sink order (lib.rs:199-254), so Phase A is split.  After the halo exchange:
+ *   cs_spawn_probe   flags[s] = 1 iff this tile owns sink s, its generator fired and nobody
+ *                    (owned agent or ghost) stands within 0.4 of its source; returns the
+ *                    number of sinks (SIZE_MAX on error)
+ *   (the caller ORs the flag vectors of all tiles: one small all-reduce)
+ *   cs_spawn_commit  assigns ids in ascending handle order over the combined flags and appends
+ *                    the agents of the sinks this tile owns
+ * then cs_step.  Generators must be deterministic across tiles (MONOTONIC, POISSON_SEEDED). */
+size_t cs_spawn_probe(cs_engine*, double dt_seconds, uint8_t* flags, size_t cap);
+int cs_spawn_commit(cs_engine*, const uint8_t* flags, size_t n);
 
 #ifdef __cplusplus
 }

@@ -870,6 +870,14 @@ int cs_halo_unpack(cs_engine* e, uint32_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+size_t cs_spawn_probe(cs_engine* e, double, uint8_t*, size_t) {
+  e->error = "oracle has no tiles";
+  return SIZE_MAX;
+}
+int cs_spawn_commit(cs_engine* e, const uint8_t*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 
 // Oracle-only probes used by tests/test_oracle_reference_kats.py to pin the
 // private pieces the reference's own unit tests reach (zanlungo.rs:225-236).

@@ -117,6 +117,8 @@ SYMBOLS = {
                                       C.c_uint64]),
     "cs_halo_pack": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cs_halo_unpack": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "cs_spawn_probe": (C.c_size_t, [C.c_void_p, C.c_double, C.POINTER(C.c_uint8), C.c_size_t]),
+    "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
 }
 
 

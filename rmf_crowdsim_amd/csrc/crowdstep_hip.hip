@@ -316,13 +316,36 @@ __global__ void k_count(AgentArrays a, uint32_t first, uint32_t n, uint32_t* __r
 __global__ void k_mark_sources(GridDev g, AgentArrays a, uint32_t n, const SinkDev* __restrict__ sinks,
                                const uint32_t* __restrict__ src_cell_start,
                                const uint32_t* __restrict__ src_sorted,
-                               uint32_t* __restrict__ src_occupied) {
+                               uint32_t* __restrict__ src_occupied, const Counters* __restrict__ ctr) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (g.tile && i >= ctr->n_pending)) return;
   uint32_t c = a.cell[i];
   if (c == CS_INVALID_CELL) return;
   float2 o = a.off[i];
   mark_sources(g, sinks, src_cell_start, src_sorted, src_occupied, c, o.x, o.y);
+}
+
+// Tile engines: append agents whose ids were assigned across tiles (cs_spawn_commit).
+struct SpawnRecord {
+  float ox, oy;
+  uint32_t id, cell, meta, pad;
+};
+__global__ void k_append_spawns(AgentArrays a, uint32_t slot_cap, const SpawnRecord* __restrict__ rec,
+                                uint32_t n, uint32_t* __restrict__ cell_count, Counters* __restrict__ ctr) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SpawnRecord r = rec[i];
+  const uint32_t slot = atomicAdd(&ctr->n_pending, 1u);
+  if (slot >= slot_cap) {
+    atomicAdd(&ctr->n_halo_overflow, 1u);
+    return;
+  }
+  a.off[slot] = make_float2(r.ox, r.oy);
+  a.vel[slot] = make_float2(0.0f, 0.0f);
+  a.id[slot] = r.id;
+  a.cell[slot] = r.cell;
+  a.meta[slot] = r.meta;
+  a.rank[slot] = atomicAdd(&cell_count[r.cell], 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -528,8 +551,8 @@ __device__ __forceinline__ void step_epilogue(const StepParams& P, const Epilogu
       double wxg = E.waypoints[2 * (s.wp_begin + next_wp)];
       double wyg = E.waypoints[2 * (s.wp_begin + next_wp) + 1];
       // waypoint relative to this agent's cell origin, rounded once to f32
-      float rx = (float)(wxg - (E.grid_off_x + (double)gx * E.cell_size));
-      float ry = (float)(wyg - (E.grid_off_y + (double)gy * E.cell_size));
+      float rx = (float)(wxg - (E.grid_off_x + (double)(P.g.org_x + gx) * E.cell_size));
+      float ry = (float)(wyg - (E.grid_off_y + (double)(P.g.org_y + gy) * E.cell_size));
       float ddx = off.x - rx, ddy = off.y - ry;
       if (sqrtf(ddx * ddx + ddy * ddy) < s.radius_sink) {
         atomicAdd(&E.ctr->n_waypoint_hits, 1u);
@@ -1668,6 +1691,10 @@ struct cs_engine {
   uint32_t* spawned_slots_dev = nullptr;
   bool sinks_dirty = true;
   uint32_t n_live_sinks = 0;
+  bool spawn_committed = false;          // tile engines: Phase A ran through cs_spawn_probe/commit
+  uint32_t committed_spawns = 0;
+  SpawnRecord* spawn_rec_dev = nullptr;
+  uint32_t spawn_rec_cap = 0;
 
   uint64_t next_id = 0;  // last_alloc_agent_id, lib.rs:83
   uint64_t n_alive_host = 0;
@@ -1965,7 +1992,7 @@ struct cs_engine {
     HIP_OK(hipMemsetAsync(src_occupied, 0, std::max<size_t>(sinks.size(), 1) * sizeof(uint32_t), stream));
     if (n_slots)
       hipLaunchKernelGGL(k_mark_sources, dim3((n_slots + 255) / 256), dim3(256), 0, stream, gdev,
-                         buf[cur], n_slots, sinks_dev, src_cell_start, src_sorted, src_occupied);
+                         buf[cur], n_slots, sinks_dev, src_cell_start, src_sorted, src_occupied, ctr);
     HIP_OK(hipGetLastError());
     occ_valid = true;
     return 0;
@@ -2093,6 +2120,111 @@ struct cs_engine {
     return rc;
   }
 
+  // CrowdGenerator::get_number_to_spawn for every live sink, ascending handle (lib.rs:199-222);
+  // want[s] = 1 iff the generator asked for at least one agent.  Returns the number of 1s.
+  uint32_t eval_generators(double dt_seconds, uint32_t* want) {
+    uint32_t n_want = 0;
+    for (size_t s = 0; s < sinks.size(); ++s) {
+      HostSink& h = sinks[s];
+      want[s] = 0;
+      if (!h.alive) continue;
+      uint64_t call = h.calls++;
+      uint64_t nsp = 0;
+      switch (h.d.generator_kind) {
+        case CS_GEN_MONOTONIC: {  // (dt * rate).round() as usize, source_sink.rs:96-100
+          double v = std::round(dt_seconds * h.d.rate);
+          nsp = v > 0 ? (uint64_t)v : 0;
+          break;
+        }
+        case CS_GEN_POISSON_SEEDED:
+          nsp = poisson_seeded(h.d.seed, call, dt_seconds * h.d.rate);
+          break;
+        case CS_GEN_CALLBACK:
+          nsp = h.d.generator ? (uint64_t)h.d.generator(h.d.generator_user, dt_seconds) : 0;
+          break;
+      }
+      want[s] = nsp > 0 ? 1u : 0u;  // the loop over n is commented out (lib.rs:207)
+      n_want += want[s];
+    }
+    return n_want;
+  }
+
+  // ---- tile engines: Phase A split in two so that ids follow the GLOBAL sink order ----
+  // probe: flags[s] = 1 iff sink s is owned by this tile, its generator fired and nobody (owned
+  // agent or ghost) stands within 0.4 of its source.
+  int spawn_probe(double dt_seconds, uint8_t* flags) {
+    if (int rc = upload_sinks()) return rc;
+    if (int rc = upload_groups()) return rc;
+    std::memset(flags, 0, sinks.size());
+    uint32_t n_want = eval_generators(dt_seconds, want_host);
+    if (!n_want) return 0;
+    occ_valid = false;  // ghosts arrived since the step kernel marked its own agents
+    if (int rc = mark_occupancy()) return rc;
+    std::vector<uint32_t> occ(sinks.size());
+    HIP_OK(hipMemcpyAsync(occ.data(), src_occupied, sinks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<SinkDev> dummy;
+    for (size_t s = 0; s < sinks.size(); ++s) {
+      if (!want_host[s] || occ[s]) continue;
+      uint32_t c;
+      float ox, oy;
+      if (to_cell(sinks[s].d.source_x, sinks[s].d.source_y, &c, &ox, &oy) == 0) flags[s] = 1;
+    }
+    return 0;
+  }
+  // commit: `flags` is the OR over all tiles.  Ids are next_id + rank in ascending handle order;
+  // this tile appends the agents of the sinks it owns.
+  int spawn_commit(const uint8_t* flags) {
+    std::vector<SpawnRecord> mine;
+    uint64_t id = next_id;
+    for (size_t s = 0; s < sinks.size(); ++s) {
+      if (!flags[s]) continue;
+      const uint64_t my_id = id++;
+      uint32_t c;
+      float ox, oy;
+      if (to_cell(sinks[s].d.source_x, sinks[s].d.source_y, &c, &ox, &oy) != 0) continue;
+      if (my_id >= 0xFFFFFFFFull) {
+        error = "agent id space exhausted (device ids are 32-bit)";
+        return 4;
+      }
+      mine.push_back(SpawnRecord{ox, oy, (uint32_t)my_id, c, sinks[s].group, 0u});
+      if (record_events) {
+        cs_event ev;
+        ev.kind = CS_EVENT_SPAWNED;
+        ev.source_sink = (uint32_t)s;
+        ev.id = my_id;
+        ev.x = sinks[s].d.source_x;
+        ev.y = sinks[s].d.source_y;
+        events.push_back(ev);
+      }
+      const cs_hlp_desc& p = hlps[sinks[s].d.hlp];
+      if (p.kind == CS_HLP_CALLBACK && p.set_target && !sinks[s].waypoints.empty())
+        p.set_target(p.user, my_id, sinks[s].d.source_x, sinks[s].d.source_y, sinks[s].waypoints[0],
+                     sinks[s].waypoints[1], sinks[s].d.radius_sink, sinks[s].d.radius_sink);
+    }
+    next_id = id;
+    committed_spawns = (uint32_t)mine.size();
+    spawn_committed = true;
+    if (mine.empty()) return 0;
+    if (int rc = recount()) return rc;
+    if (int rc = reserve((uint64_t)n_slots + mine.size())) return rc;
+    if (mine.size() > spawn_rec_cap) {
+      hipFree(spawn_rec_dev);
+      spawn_rec_cap = (uint32_t)mine.size() * 2u + 64u;
+      HIP_OK(hipMalloc(&spawn_rec_dev, (size_t)spawn_rec_cap * sizeof(SpawnRecord)));
+    }
+    HIP_OK(hipMemcpyAsync(spawn_rec_dev, mine.data(), mine.size() * sizeof(SpawnRecord),
+                          hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_append_spawns, dim3(((uint32_t)mine.size() + 255) / 256), dim3(256), 0, stream,
+                       buf[cur], (uint32_t)cap, spawn_rec_dev, (uint32_t)mine.size(), cell_count, ctr);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(stream));  // `mine` dies at return
+    n_slots += (uint32_t)mine.size();
+    sorted = false;
+    return 0;
+  }
+
   // ---- Simulation::step, lib.rs:195-383 ----
   int step(double dt_seconds, cs_step_report* report) {
     if (poisoned) {
@@ -2102,8 +2234,8 @@ struct cs_engine {
     if (int rc = upload_sinks()) return rc;
     if (int rc = upload_groups()) return rc;
     const bool has_sinks = n_live_sinks > 0;
-    if (tile && has_sinks) {
-      error = "source-sinks are not supported on a tile engine yet (spawn ids need a cross-tile order)";
+    if (tile && has_sinks && !spawn_committed) {
+      error = "tile engine with source-sinks: run cs_spawn_probe / cs_spawn_commit before cs_step";
       return 6;
     }
     // a tile's slot count changes with every halo exchange: the host re-reads it each step
@@ -2116,30 +2248,9 @@ struct cs_engine {
     uint32_t n_want = 0;
     bool spawn_events_done = false;
     const uint64_t first_spawn_id = next_id;
-    if (has_sinks) {
+    if (has_sinks && !tile) {
       uint32_t* want = want_host;  // the previous step ended with a sync: its copy is done
-      for (size_t s = 0; s < sinks.size(); ++s) {
-        HostSink& h = sinks[s];
-        want[s] = 0;
-        if (!h.alive) continue;
-        uint64_t call = h.calls++;
-        uint64_t nsp = 0;
-        switch (h.d.generator_kind) {
-          case CS_GEN_MONOTONIC: {  // (dt * rate).round() as usize, source_sink.rs:96-100
-            double v = std::round(dt_seconds * h.d.rate);
-            nsp = v > 0 ? (uint64_t)v : 0;
-            break;
-          }
-          case CS_GEN_POISSON_SEEDED:
-            nsp = poisson_seeded(h.d.seed, call, dt_seconds * h.d.rate);
-            break;
-          case CS_GEN_CALLBACK:
-            nsp = h.d.generator ? (uint64_t)h.d.generator(h.d.generator_user, dt_seconds) : 0;
-            break;
-        }
-        want[s] = nsp > 0 ? 1u : 0u;  // the loop over n is commented out (lib.rs:207)
-        n_want += want[s];
-      }
+      n_want = eval_generators(dt_seconds, want);
       if (n_want) {
         if (next_id + n_want >= 0xFFFFFFFFull) {
           error = "agent id space exhausted (device ids are 32-bit)";
@@ -2311,7 +2422,7 @@ struct cs_engine {
     if (!spawn_events_done)
       if (int rc = finish_spawn_events(c.n_spawned, first_spawn_id)) return rc;
     if (int rc = finish_destroy_events(c)) return rc;
-    n_alive_host = tile ? (uint64_t)c.n_owned : (uint64_t)c.n_alive - c.n_destroyed;
+    n_alive_host = tile ? (uint64_t)c.n_owned - c.n_destroyed : (uint64_t)c.n_alive - c.n_destroyed;
     if (c.n_halo_overflow) {
       error = "halo buffer overflow: raise capacity_records of cs_halo_set_buffers";
       poisoned = true;
@@ -2319,13 +2430,15 @@ struct cs_engine {
     }
     if (report) {
       report->n_agents = n_alive_host;
-      report->n_spawned = c.n_spawned;
+      report->n_spawned = tile ? committed_spawns : c.n_spawned;
       report->n_destroyed = c.n_destroyed;
       report->n_waypoint_hits = c.n_waypoint_hits;
       report->n_tti_zero = c.n_tti_zero;
       report->n_nonfinite = c.n_nonfinite;
       report->n_clamped = c.n_clamped;
     }
+    spawn_committed = false;
+    committed_spawns = 0;
     return 0;
   }
 
@@ -2457,7 +2570,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->spawn_rec_dev);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -2814,6 +2927,25 @@ int cs_halo_set_buffers(cs_engine* e, uint32_t dir, void* send_dev, void* recv_d
   e->halo[dir].cap = (uint32_t)capacity_records;
   // room for everything the four neighbours may deliver in one step
   return e->reserve((uint64_t)e->n_slots + 1024);
+}
+
+size_t cs_spawn_probe(cs_engine* e, double dt_seconds, uint8_t* flags, size_t cap) {
+  hipSetDevice(e->device);
+  if (!e->tile || cap < e->sinks.size()) {
+    e->error = "cs_spawn_probe needs a tile engine and room for one flag per source-sink";
+    return SIZE_MAX;
+  }
+  if (e->spawn_probe(dt_seconds, flags) != 0) return SIZE_MAX;
+  return e->sinks.size();
+}
+
+int cs_spawn_commit(cs_engine* e, const uint8_t* flags, size_t n) {
+  hipSetDevice(e->device);
+  if (!e->tile || n != e->sinks.size()) {
+    e->error = "cs_spawn_commit needs a tile engine and one flag per source-sink";
+    return 3;
+  }
+  return e->spawn_commit(flags);
 }
 
 int cs_halo_pack(cs_engine* e, uint32_t axis) {

@@ -448,6 +448,22 @@ class Simulation:
         if self._lib.cs_halo_unpack(self._engine, int(axis)) != 0:
             raise self._err()
 
+    def spawn_probe(self, dur):
+        """Tile engines: which of MY source-sinks would spawn this step (uint8 flag per sink)."""
+        dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
+        flags = np.zeros(max(len(self._source_sinks), 1), dtype=np.uint8)
+        n = self._lib.cs_spawn_probe(self._engine, dt, flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                     len(flags))
+        if n == C.c_size_t(-1).value:
+            raise self._err()
+        return flags[:n]
+
+    def spawn_commit(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        if self._lib.cs_spawn_commit(self._engine, flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                     len(flags)) != 0:
+            raise self._err()
+
     # -- measurement --
     def profile_enable(self, kernel_mask=0xFFFFFFFF):
         """Bit k times kernel CS_K_k with hipEvents on the engine's stream; 0 = off."""

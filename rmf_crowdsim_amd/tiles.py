@@ -130,6 +130,17 @@ class LocalTileMesh(_TileBase):
             ids = sim.add_agents(positions, high_level_planner, local_planner, eyesight)
         return ids
 
+    def add_source_sink(self, source_sink):
+        handle = None
+        for sim in self.engines:  # every tile registers every sink; the owner of the source spawns
+            handle = sim.add_source_sink(source_sink)
+        self._has_sinks = True
+        return handle
+
+    def add_event_listener(self, listener):
+        for sim in self.engines:
+            sim.add_event_listener(listener)
+
     def _exchange(self, axis):
         for sim in self.engines:
             sim.halo_pack(axis)
@@ -147,6 +158,13 @@ class LocalTileMesh(_TileBase):
     def step(self, dur, report=True):
         self._exchange(0)
         self._exchange(1)
+        if getattr(self, "_has_sinks", False):
+            flags = None
+            for sim in self.engines:
+                f = sim.spawn_probe(dur)
+                flags = f if flags is None else (flags | f)
+            for sim in self.engines:
+                sim.spawn_commit(flags)
         for sim in self.engines:
             sim.step(dur, report=report)
 
@@ -214,12 +232,23 @@ class DistributedTiles(_TileBase):
     def add_agents(self, positions, high_level_planner, local_planner, eyesight):
         return self.sim.add_agents(positions, high_level_planner, local_planner, eyesight)
 
+    def add_source_sink(self, source_sink):
+        self._has_sinks = True
+        return self.sim.add_source_sink(source_sink)
+
     def step(self, dur, report=False):
         with self.torch.cuda.stream(self.stream):
             for axis in (0, 1):
                 self.sim.halo_pack(axis)
                 exchange_axis(self.dist, self.layout, self.index, self.bufs, axis)
                 self.sim.halo_unpack(axis)
+        if getattr(self, "_has_sinks", False):
+            # ids follow the global sink order: OR the per-tile spawn flags (one small all-reduce)
+            flags = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))
+            if self.dist.get_backend() == "nccl":
+                flags = flags.cuda()
+            self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
+            self.sim.spawn_commit(flags.cpu().numpy().astype(np.uint8))
         self.sim.step(dur, report=report)
 
     def read_agents(self):

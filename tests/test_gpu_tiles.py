@@ -127,3 +127,41 @@ def test_distributed_tiles_two_ranks(tmp_path):
         single.step(0.05, report=False)
     a = single.read_agents()
     assert len(both) == n and a.tobytes() == both.tobytes()
+
+
+# ---- source-sinks on tiles: ids must follow the global sink order -------------------------
+def _sink_scene(target):
+    from rmf_crowdsim_amd import SeededPoissonCrowd, SourceSink
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    plans = {}
+    slope = 0.15 / 1.29
+    for k in range(18):
+        # parallel slanted lanes 2 m apart, alternating direction: every lane starts in one tile and
+        # ends in another (several cross the corner); opposing walkers pass 2 m apart and never
+        # collide, but see each other (ghosts matter)
+        x0 = 8.0 + 2.0 * k
+        up = k % 2 == 0
+        lo, hi = (x0, 8.0), (x0 + slope * 44.0, 52.0)
+        src, dst, vel = (lo, hi, (0.15, 1.29)) if up else (hi, lo, (-0.15, -1.29))
+        hlp = plans.setdefault(vel, StubHighLevelPlan(vel))
+        target.add_source_sink(SourceSink(src, 0.8, SeededPoissonCrowd(4.0, 500 + k), hlp, lp, [dst], False, 2.0))
+
+
+@pytest.mark.parametrize("tiles", [(2, 2), (3, 1)])
+def test_source_sinks_across_tiles_match_single_engine(tiles):
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1)
+    for t in (single, mesh):
+        _sink_scene(t)
+    counts_s, counts_m = [], []
+    for k in range(800):
+        single.step(0.05)
+        mesh.step(0.05)
+        counts_s.append((len(single), single.last_report["n_spawned"], single.last_report["n_destroyed"]))
+        counts_m.append((len(mesh), sum(e.last_report["n_spawned"] for e in mesh.engines),
+                         sum(e.last_report["n_destroyed"] for e in mesh.engines)))
+    assert counts_s == counts_m
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and sum(c[2] for c in counts_s) > 100  # agents were born, walked across, and left
+    assert a.tobytes() == b.tobytes()
