@@ -107,24 +107,33 @@ def main():
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
-        if world != 1:
-            raise SystemExit("source-sinks are single-GPU for now (DESIGN.md section 7)")
         from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
-        tiling = (1, 1)
-        lanes, grid, fill_steps = scenes.stream_lanes(args.agents, cell_size=args.cell)
+        # longer lanes on more GPUs keep the number of sinks (one planner group each) under 65535
+        lane_length = 16.0 * max(1, (world + 1) // 2)
+        lanes, grid, fill_steps = scenes.stream_lanes(args.agents * world, lane_length=lane_length,
+                                                      cell_size=args.cell)
         extent = grid["width"]
-        sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
-                         stream=torch.cuda.current_stream().cuda_stream,
-                         capacity_hint=int(args.agents * 1.2) + 4096)
+        if world == 1:
+            tiling = (1, 1)
+            sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
+                             stream=torch.cuda.current_stream().cuda_stream,
+                             capacity_hint=int(args.agents * 1.2) + 4096)
+            stepper = sim
+        else:
+            tiling = default_tiling(world)
+            halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
+            stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
+                                       density_per_cell=1.5 * scenes.METRIC_DENSITY * args.cell ** 2,
+                                       capacity_hint=int(args.agents * 1.3) + 4096, flags=flags)
+            sim = stepper.sim
         plans = {}
         for src, dst, vel in lanes:
             hlp = plans.setdefault(vel, StubHighLevelPlan(vel))
-            sim.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False,
-                                           args.eyesight))
+            stepper.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False,
+                                               args.eyesight))
         n_sinks = len(lanes)
-        stepper = sim
         for _ in range(fill_steps):
-            sim.step(0.05, report=False)
+            stepper.step(0.05, report=False)
         speed = scenes.WALK_SPEED
     elif world == 1:
         tiling = (1, 1)
@@ -182,7 +191,10 @@ def main():
         rep = sim.last_report
     total_agents = args.agents * world
     if args.workload == "stream":
-        total_agents = rep["n_agents"]  # what the sinks actually sustain
+        t_n = torch.tensor([rep["n_agents"]], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t_n)
+        total_agents = int(t_n.item())  # what the sinks actually sustain, over all tiles
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
     ncells = int(round(grid["width"] / grid["cell_size"])) ** 2 // world  # per tile
@@ -220,7 +232,7 @@ def main():
                              f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
                              f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s")
                 if args.workload == "uniform" else
-                (f"~{args.agents} agents sustained by {n_sinks} source-sinks (MonotonicCrowd, 16 m lanes 1 m "
+                (f"~{args.agents} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m "
                  f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
                 "n_spawned_last_step": rep.get("n_spawned"), "n_destroyed_last_step": rep.get("n_destroyed"),
