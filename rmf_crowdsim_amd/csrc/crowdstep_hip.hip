@@ -602,13 +602,12 @@ __device__ __forceinline__ void step_epilogue(const StepParams& P, const Epilogu
 // ---------------------------------------------------------------------------
 // K4: the neighbour pass.  Phase B of Simulation::step for one agent
 // (lib.rs:259-347): radius query (location_hash_2d.rs:240-258), Zanlungo
-// (zanlungo.rs:201-217).  One code path, two neighbour sources:
-//   TiledSrc   cell lists staged in LDS by the workgroup (the fast path)
-//   GatherSrc  cell lists read from global memory (exact for any grid and any
-//              agent state: clamped, aliased, overfull tiles)
-// Both visit cells x-major / y-minor and the members of a cell in ascending id
-// (the canonical order of SURVEY.md §8a'), with identical arithmetic, so their
-// results are bitwise equal.
+// (zanlungo.rs:201-217).  Two forms with the same arithmetic and the same visiting order (cells
+// x-major / y-minor, members of a cell in ascending id: the canonical order of SURVEY.md §8a'),
+// so their results are bitwise equal:
+//   k_step_tiled   cell lists staged in LDS by the workgroup, per-lane neighbour lists (fast path)
+//   GatherSrc      cell lists read from global memory (exact for any grid and any agent state:
+//                  clamped, aliased, overfull tiles); k_step_gather and the fallback in k_step_tiled
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float2 hlp_velocity(const GroupDev& grp, uint32_t id, const float2* pref,
                                                uint32_t i) {
@@ -674,32 +673,6 @@ struct GatherSrc {
     last = best;
     have_last = true;
     return bj;
-  }
-};
-
-// Members of one cell from the workgroup's LDS tile (already in ascending id).
-struct TiledSrc {
-  const float2* __restrict__ s_off;
-  const float2* __restrict__ s_vel;
-  const uint32_t* __restrict__ s_id;
-  const unsigned short* __restrict__ s_tab;  // [row][W + 1] first LDS slot of each staged cell
-  int r0, r1;  // staged rows
-  int sy0, sy1;  // staged cells of every row
-  int W1;        // W + 1
-  uint32_t self_id;
-  __device__ __forceinline__ bool cell(long long x, long long y, uint32_t& b, uint32_t& e) const {
-    if (x < r0 || x > r1 || y < sy0 || y > sy1) return false;
-    const unsigned short* t = s_tab + (int)(x - r0) * W1 + (int)(y - sy0);
-    b = t[0];
-    e = t[1];
-    return true;
-  }
-  __device__ __forceinline__ bool is_self(uint32_t j) const { return s_id[j] == self_id; }
-  __device__ __forceinline__ float2 off(uint32_t j, long long, long long) const { return s_off[j]; }
-  __device__ __forceinline__ float2 vel(uint32_t j) const { return s_vel[j]; }
-  __device__ __forceinline__ uint32_t id(uint32_t j) const { return s_id[j]; }
-  __device__ __forceinline__ uint32_t ordered(uint32_t b, uint32_t, uint32_t k, uint32_t&, bool&) const {
-    return b + k;
   }
 };
 
