@@ -214,6 +214,7 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
 // Simulation::remove_agents, lib.rs:176-192
 int cs_remove_agent(cs_engine* e, uint64_t id) {
   hipSetDevice(e->device);
+  if (int rc = e->refresh_counts()) return rc;
   cs_engine::HostState h;
   if (int rc = e->download(&h)) return rc;
   for (uint32_t i = 0; i < e->n_slots; ++i) {
@@ -275,6 +276,7 @@ int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
 
 int cs_synchronize(cs_engine* e) {
   hipSetDevice(e->device);
+  if (int rc = e->refresh_counts()) return rc;
   Counters c;
   if (int rc = e->read_counters(&c)) return rc;
   e->prof_collect();
@@ -286,10 +288,15 @@ int cs_synchronize(cs_engine* e) {
   return 0;
 }
 
-size_t cs_agent_count(cs_engine* e) { return (size_t)e->n_alive_host; }
+size_t cs_agent_count(cs_engine* e) {
+  hipSetDevice(e->device);
+  e->refresh_counts();
+  return (size_t)e->n_alive_host;
+}
 
 size_t cs_read_agents(cs_engine* e, cs_agent_view* out, size_t cap) {
   hipSetDevice(e->device);
+  if (e->refresh_counts() != 0) return 0;
   cs_engine::HostState h;
   if (e->download(&h) != 0) return 0;
   std::vector<uint32_t> live;
@@ -317,6 +324,8 @@ size_t cs_drain_events(cs_engine* e, cs_event* out, size_t cap) {
 }
 
 void cs_event_recording(cs_engine* e, int on) {
+  hipSetDevice(e->device);
+  e->refresh_counts();
   e->record_events = on != 0;
   if (!on) e->events.clear();
 }
@@ -324,6 +333,7 @@ void cs_event_recording(cs_engine* e, int on) {
 // SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258
 size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap) {
   hipSetDevice(e->device);
+  if (e->refresh_counts() != 0) return 0;
   if (e->ensure_index() != 0) return 0;
   // get_bounds (:103-122) in f64 on the global query point
   auto fl = [&](double v, double o) -> long long {
@@ -370,6 +380,7 @@ size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t
 // ties by ascending id.
 size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_ids) {
   hipSetDevice(e->device);
+  if (e->refresh_counts() != 0) return 0;
   cs_engine::HostState h;
   if (e->download(&h) != 0) return 0;
   std::vector<std::pair<double, uint64_t>> d;

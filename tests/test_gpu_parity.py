@@ -450,3 +450,34 @@ def test_callback_planner_gets_set_target_and_remove():
             assert a[3] == b[3] and a[4] == b[4] and abs(a[2] - b[2]) < 1e-3
     assert (finals[0]["id"] == finals[1]["id"]).all()
     assert np.abs(finals[0]["x"] - finals[1]["x"]).max() < 1e-3
+
+
+def test_source_sink_steps_without_host_sync_match_synced_steps():
+    """With source-sinks but no listener / report the engine runs steps fire-and-forget (slot
+    counts and the id counter stay on the device, the host catches up lazily).  Same result as
+    stepping with a report every step, and as the oracle."""
+    def build(cls):
+        grid = dict(width=120.0, height=120.0, cell_size=2.0, offset=(0.0, 0.0))
+        sim = cls(LocationHash2D(**grid))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        for k in range(24):
+            y = 10.0 + 2.5 * k
+            left = k % 2 == 0
+            sim.add_source_sink(SourceSink((10.0, y) if left else (110.0, y), 1.0,
+                                           SeededPoissonCrowd(3.0, 900 + k),
+                                           StubHighLevelPlan((1.3, 0.0) if left else (-1.3, 0.0)), lp,
+                                           [(60.0, y) if left else (62.0, y)], False, 2.0))
+        return sim
+    lazy, eager, ora = build(Simulation), build(Simulation), build(OracleSimulation)
+    for k in range(900):
+        lazy.step(0.05, report=False)
+        eager.step(0.05, report=True)
+        ora.step(0.05)
+        if k in (17, 400):  # host-side calls in the middle of a lazy stretch must catch up first
+            assert len(lazy) == len(eager) == len(ora)
+    extra = lazy.add_agents([(100.0, 100.0)], StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0)
+    assert extra == eager.add_agents([(100.0, 100.0)], StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0) \
+        == ora.add_agents([(100.0, 100.0)], StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0)
+    a, b, c = lazy.read_agents(), eager.read_agents(), ora.read_agents()
+    assert len(a) > 300 and a.tobytes() == b.tobytes()
+    assert (a["id"] == c["id"]).all() and max_rel_err(a, c, 120.0) <= 1e-4
