@@ -204,12 +204,14 @@ def main():
     # HBM traffic of the kernel from the PMC counters (separate rocprofv3 passes, FETCH_SIZE x2 on
     # gfx950): measured offline for the default workload and kept under profiles/
     traffic = None
+    valu_insts = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "k4_traffic.json")) as f:
             tr = json.load(f)
         if (tr["agents"], tr["cell"], tr["eyesight"]) == (args.agents, args.cell, args.eyesight) \
                 and args.kernel != "gather" and not args.debug and args.workload == "uniform" and world == 1:
             traffic = tr["traffic_bytes_per_launch"]
+            valu_insts = tr.get("valu_wave_insts_per_launch")
     except (OSError, KeyError, ValueError):
         pass
 
@@ -251,6 +253,10 @@ def main():
                         "LDS-latency bound at this neighbour count (DESIGN.md section 4)",
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
                 "kernel_ms": k4_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                # what actually bounds it: wave64 VALU instructions (PMC, profiles/r01) against the
+                # chip's issue rate of one per 2 clocks per SIMD (1024 SIMDs, 2.4 GHz)
+                "valu_issue_frac": (valu_insts / (k4_ms * 1e-3) / (1024 * 2.4e9 / 2.0))
+                if (valu_insts and k4_ms > 0) else None,
             },
         }
         if not args.no_cpu_baseline:

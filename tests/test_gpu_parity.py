@@ -481,3 +481,25 @@ def test_source_sink_steps_without_host_sync_match_synced_steps():
     a, b, c = lazy.read_agents(), eager.read_agents(), ora.read_agents()
     assert len(a) > 300 and a.tobytes() == b.tobytes()
     assert (a["id"] == c["id"]).all() and max_rel_err(a, c, 120.0) <= 1e-4
+
+
+@pytest.mark.parametrize("loop_forever", [True, False])
+def test_multi_waypoint_route_and_loop_forever(loop_forever):
+    """lib.rs:304-336: waypoints are tested on the OLD position with a strict `<`; the last one
+    either wraps next_waypoint to 0 (loop_forever, no set_target) or removes the agent."""
+    out = []
+    for cls in (Simulation, OracleSimulation):
+        sim = cls(LocationHash2D(200.0, 200.0, 5.0, (-100.0, -100.0)))
+        sim.add_source_sink(SourceSink((0.0, 0.0), 1.0, MonotonicCrowd(10.0), StubHighLevelPlan((2.0, 0.0)),
+                                       NoLocalPlan(), [(5.0, 0.0), (10.0, 0.0), (15.0, 0.0)], loop_forever, 2.0))
+        trace = []
+        for _ in range(120):
+            sim.step(0.1)
+            a = sim.read_agents()
+            trace.append((len(a), tuple(int(v) for v in a["next_waypoint"][:6]), sim.last_report["n_waypoint_hits"],
+                          sim.last_report["n_destroyed"]))
+        out.append((trace, sim.read_agents()))
+    assert out[0][0] == out[1][0]
+    assert np.allclose(out[0][1]["x"], out[1][1]["x"], atol=1e-4)
+    hits = sum(t[2] for t in out[0][0])
+    assert hits > 20 and (sum(t[3] for t in out[0][0]) == 0) == loop_forever
