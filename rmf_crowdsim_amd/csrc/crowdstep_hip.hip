@@ -330,9 +330,14 @@ void cs_event_recording(cs_engine* e, int on) {
   if (!on) e->events.clear();
 }
 
-// SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258
-size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap) {
-  hipSetDevice(e->device);
+// Radius query on the device index: ids in reference cell order (x-major, y-minor, ascending id
+// inside a cell) and their squared distances.  Returns the full count.
+static size_t radius_query(cs_engine* e, double radius, double x, double y, std::vector<uint32_t>* ids,
+                           std::vector<float>* d2, size_t cap) {
+  if (e->tile) {
+    e->error = "spatial queries are not available on a tile engine";
+    return 0;
+  }
   if (e->refresh_counts() != 0) return 0;
   if (e->ensure_index() != 0) return 0;
   // get_bounds (:103-122) in f64 on the global query point
@@ -352,47 +357,77 @@ size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t
   long long qy = std::min(std::max(fl(y, e->grid.offset_y), 0ll), (long long)e->nx - 1);
   float qox = (float)((x - e->grid.offset_x) - (double)qx * e->grid.cell_size);
   float qoy = (float)((y - e->grid.offset_y) - (double)qy * e->grid.cell_size);
-  uint32_t qcap = (uint32_t)std::min<size_t>(cap, 1u << 20);
+  uint32_t qcap = (uint32_t)std::max<size_t>(1, std::min<size_t>(cap, 1u << 22));
   uint32_t* d_out = nullptr;
+  float* d_d2 = nullptr;
   uint32_t* d_cnt = nullptr;
-  if (hipMalloc(&d_out, std::max<uint32_t>(qcap, 1) * sizeof(uint32_t)) != hipSuccess) return 0;
-  if (hipMalloc(&d_cnt, sizeof(uint32_t)) != hipSuccess) {
-    hipFree(d_out);
+  bool ok = hipMalloc(&d_out, qcap * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&d_d2, qcap * sizeof(float)) == hipSuccess &&
+            hipMalloc(&d_cnt, sizeof(uint32_t)) == hipSuccess;
+  uint32_t cnt = 0;
+  if (ok) {
+    hipLaunchKernelGGL(k_query_radius, dim3(1), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
+                       e->cell_start, lx, hx, ly, hy, (uint32_t)qx, (uint32_t)qy, qox, qoy, (float)radius,
+                       d_out, d_d2, qcap, d_cnt);
+    ok = hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipStreamSynchronize(e->stream) == hipSuccess;
+    uint32_t m = ok ? std::min(cnt, qcap) : 0;
+    ids->resize(m);
+    d2->resize(m);
+    if (m) {
+      ok = ok && hipMemcpy(ids->data(), d_out, m * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && hipMemcpy(d2->data(), d_d2, m * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+  }
+  hipFree(d_out);
+  hipFree(d_d2);
+  hipFree(d_cnt);
+  if (!ok) {
+    e->error = "HIP error in a spatial query";
+    ids->clear();
+    d2->clear();
     return 0;
   }
-  hipLaunchKernelGGL(k_query_radius, dim3(1), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
-                     e->cell_start, lx, hx, ly, hy, (uint32_t)qx, (uint32_t)qy, qox, qoy, (float)radius,
-                     d_out, qcap, d_cnt);
-  uint32_t cnt = 0;
-  hipMemcpyAsync(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, e->stream);
-  hipStreamSynchronize(e->stream);
-  uint32_t m = std::min(cnt, qcap);
-  std::vector<uint32_t> ids(m);
-  if (m) hipMemcpy(ids.data(), d_out, m * sizeof(uint32_t), hipMemcpyDeviceToHost);
-  for (uint32_t i = 0; i < m; ++i) out_ids[i] = ids[i];
-  hipFree(d_out);
-  hipFree(d_cnt);
   return cnt;
 }
 
-// SpatialIndex::get_nearest_neighbours, location_hash_2d.rs:151-238.  Not on the
-// step path: exact k-NN over a host copy,
-// ties by ascending id.
+// SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258
+size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap) {
+  hipSetDevice(e->device);
+  std::vector<uint32_t> ids;
+  std::vector<float> d2;
+  size_t cnt = radius_query(e, radius, x, y, &ids, &d2, cap);
+  for (size_t i = 0; i < ids.size() && i < cap; ++i) out_ids[i] = ids[i];
+  return cnt;
+}
+
+// SpatialIndex::get_nearest_neighbours, location_hash_2d.rs:151-238.  Not on the step path
+// (SURVEY.md §8a row a14).  The reference's ring search has defects (it never visits one corner
+// of a ring, visits another twice and stops as soon as it holds n candidates); this is the exact
+// k-NN instead: radius queries on the device index with a doubling radius until k agents are
+// inside, then the k smallest distances (ties by ascending id).  Cost O(neighbourhood), not O(N).
 size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_ids) {
   hipSetDevice(e->device);
-  if (e->refresh_counts() != 0) return 0;
-  cs_engine::HostState h;
-  if (e->download(&h) != 0) return 0;
-  std::vector<std::pair<double, uint64_t>> d;
-  for (uint32_t i = 0; i < e->n_slots; ++i) {
-    if (h.cell[i] == CS_INVALID_CELL) continue;
-    double px, py;
-    e->to_global(h.cell[i], h.off[i].x, h.off[i].y, &px, &py);
-    d.push_back({std::sqrt((px - x) * (px - x) + (py - y) * (py - y)), h.id[i]});
+  if (k == 0 || e->refresh_counts() != 0 || e->n_alive_host == 0) return 0;
+  const double reach = 2.0 * (std::fabs(x - e->grid.offset_x) + std::fabs(y - e->grid.offset_y) +
+                              e->grid.width + e->grid.height);
+  std::vector<uint32_t> ids;
+  std::vector<float> d2;
+  std::vector<std::pair<float, uint32_t>> by_dist;
+  double r = e->grid.cell_size;
+  for (;;) {
+    radius_query(e, r, x, y, &ids, &d2, (size_t)1 << 22);
+    // a window wider than the grid visits aliased cells twice (row stride nx on both axes,
+    // location_hash_2d.rs:59), so count distinct ids
+    by_dist.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) by_dist[i] = {d2[i], ids[i]};
+    std::sort(by_dist.begin(), by_dist.end());
+    by_dist.erase(std::unique(by_dist.begin(), by_dist.end()), by_dist.end());
+    if (by_dist.size() >= k || by_dist.size() >= e->n_alive_host || r > reach) break;
+    r *= 2.0;
   }
-  std::sort(d.begin(), d.end());
-  size_t n = std::min(k, d.size());
-  for (size_t i = 0; i < n; ++i) out_ids[i] = d[i].second;
+  size_t n = std::min(k, by_dist.size());
+  for (size_t i = 0; i < n; ++i) out_ids[i] = by_dist[i].second;
   return n;
 }
 

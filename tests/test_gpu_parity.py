@@ -503,3 +503,21 @@ def test_multi_waypoint_route_and_loop_forever(loop_forever):
     assert np.allclose(out[0][1]["x"], out[1][1]["x"], atol=1e-4)
     hits = sum(t[2] for t in out[0][0])
     assert hits > 20 and (sum(t[3] for t in out[0][0]) == 0) == loop_forever
+
+
+def test_nearest_neighbours_on_the_device_index():  # location_hash_2d.rs:311-339
+    sim = Simulation(LocationHash2D(10.0, 10.0, 0.5, (0.0, 0.0)))
+    pts = np.array([(x + 0.5, y + 0.5) for x in range(10) for y in range(10)])
+    sim.add_agents(pts, StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0)
+    assert sim.get_nearest_neighbours(1, (0.6, 0.6)) == [0]
+    q = np.array([1.7, 1.6])
+    naive = [int(i) for i in np.argsort(np.hypot(*(pts - q).T), kind="stable")[:4]]
+    assert sim.get_nearest_neighbours(4, q) == naive
+    rng = np.random.default_rng(1)
+    cloud = rng.uniform(1.0, 99.0, size=(5000, 2))
+    big = Simulation(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)))
+    big.add_agents(cloud, StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0)
+    for q in ((50.0, 50.0), (0.5, 99.5), (120.0, -3.0)):
+        d = np.hypot(cloud[:, 0] - q[0], cloud[:, 1] - q[1])
+        assert big.get_nearest_neighbours(7, q) == [int(i) for i in np.argsort(d, kind="stable")[:7]]
+    assert len(big.get_nearest_neighbours(6000, (50.0, 50.0))) == 5000
