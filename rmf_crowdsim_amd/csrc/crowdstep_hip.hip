@@ -431,6 +431,24 @@ size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_id
   return n;
 }
 
+#ifdef CS_PHASE_CLOCKS
+// profiling build only: read (and optionally clear) the per-phase wave cycles of the tiled kernel
+void cs_debug_phase_cycles(cs_engine* e, unsigned long long* out8, int reset) {
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  static unsigned long long host[PHASE_SLOTS][8];
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof host);
+  for (int k = 0; k < 8; ++k) {
+    out8[k] = 0;
+    for (int q = 0; q < PHASE_SLOTS; ++q) out8[k] += host[q][k];
+  }
+  if (reset) {
+    memset(host, 0, sizeof host);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), host, sizeof host);
+  }
+}
+#endif
+
 void cs_profile_enable(cs_engine* e, uint32_t kernel_mask) { e->profiling = kernel_mask; }
 int cs_profile_read(cs_engine* e, uint32_t kernel, double* total_ms, uint64_t* launches) {
   if (kernel >= CS_K_COUNT) return 2;
