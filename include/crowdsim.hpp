@@ -106,6 +106,31 @@ struct IdParityHighLevelPlan : StubHighLevelPlan {  // rmf_crowdsim_viz/src/main
     return d;
   }
 };
+// The follower half of RMFPlanner (rmf/mod.rs:195-242): override plan_route (the A* of
+// rmf/mod.rs:160-192 is the host's business); it is asked once per new (start, goal) hash pair,
+// following the route runs on the device.  An empty result = no contiguous path.
+struct RouteFollower : HighLevelPlanner {
+  double scale = 1.0, arrive = 0.1, speed = 1.0;
+  virtual std::vector<Point> plan_route(Point start, Point goal) = 0;
+  cs_hlp_desc describe() override {
+    cs_hlp_desc d{};
+    d.kind = CS_HLP_ROUTE;
+    d.user = this;
+    d.route_scale = scale;
+    d.route_arrive = arrive;
+    d.route_speed = speed;
+    d.route_plan = [](void* u, double sx, double sy, double gx, double gy, double* out, size_t cap) -> size_t {
+      const std::vector<Point> r = static_cast<RouteFollower*>(u)->plan_route({sx, sy}, {gx, gy});
+      const size_t n = r.size() < cap ? r.size() : cap;
+      for (size_t k = 0; k < n; ++k) {
+        out[2 * k] = r[k].x;
+        out[2 * k + 1] = r[k].y;
+      }
+      return n;
+    };
+    return d;
+  }
+};
 
 struct LocalPlanner {  // local_planner.rs:7-18: only the shipped planners run on the device
   virtual ~LocalPlanner() = default;

@@ -85,12 +85,20 @@ typedef struct cs_zanlungo_params {
  *   CONSTANT  Some(v)            (StubHighLevelPlan, lib.rs:391-420)
  *   ID_PARITY even id -> Some(-v), odd id -> Some(v)
  *             (rmf_crowdsim_viz/src/main.rs:20-30)
- *   CALLBACK  host trait object, evaluated per step for the whole batch       */
+ *   CALLBACK  host trait object, evaluated per step for the whole batch
+ *   ROUTE     RMFPlanner's follower (rmf/mod.rs:195-242) as data: the route of
+ *             an agent is planned on the host ONCE per set_target (A* itself is
+ *             the host's business, `route_plan`), cached per (start, goal) hash
+ *             pair like route_plans_by_location (rmf/mod.rs:86-88,217-236); per
+ *             step the device returns unit(route[wp] - position) * route_speed
+ *             and moves on to the next waypoint inside route_arrive (:203-209).
+ *             Agents that never got a target return None (:211-214).          */
 enum {
   CS_HLP_NONE = 0,
   CS_HLP_CONSTANT = 1,
   CS_HLP_ID_PARITY = 2,
-  CS_HLP_CALLBACK = 3
+  CS_HLP_CALLBACK = 3,
+  CS_HLP_ROUTE = 4
 };
 
 /* get_desired_velocity(&mut self, &Agent, Duration) -> Option<Vec2f> for n
@@ -106,6 +114,13 @@ typedef void (*cs_hlp_set_target_fn)(void* user, uint64_t id, double pos_x,
                                      double point_y, double tol_x, double tol_y);
 /* remove_agent_id(&mut self, AgentId)              highlevel_planners.rs:15 */
 typedef void (*cs_hlp_remove_fn)(void* user, uint64_t id);
+/* RMFPlanner::plan_route(start, goal) -> Option<Vec<Vec2f>>   rmf/mod.rs:160-192
+ * writes up to `cap` waypoints (x, y pairs, the goal last) and returns their
+ * number; 0 = "Failed to find contiguous path" (the agent then has no route). */
+typedef size_t (*cs_route_plan_fn)(void* user, double start_x, double start_y,
+                                   double goal_x, double goal_y, double* out_xy,
+                                   size_t cap);
+#define CS_ROUTE_MAX_WAYPOINTS 1023
 
 typedef struct cs_hlp_desc {
   uint32_t kind; /* CS_HLP_* */
@@ -114,6 +129,11 @@ typedef struct cs_hlp_desc {
   cs_hlp_set_target_fn set_target;
   cs_hlp_remove_fn remove_agent;
   void* user;
+  /* ROUTE */
+  cs_route_plan_fn route_plan;
+  double route_scale;  /* SpatialHash resolution of the route cache, rmf/mod.rs:70-77 */
+  double route_arrive; /* 1e-1 in the reference, rmf/mod.rs:203                      */
+  double route_speed;  /* 1.0 in the reference (a unit vector), rmf/mod.rs:209       */
 } cs_hlp_desc;
 
 /* CrowdGenerator::get_number_to_spawn(&self, Duration) -> usize

@@ -43,7 +43,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -403,9 +405,36 @@ struct Zanlungo : LocalPlanner {
 // ---------------------------------------------------------------------------
 struct HighLevelPlanner {
   cs_hlp_desc d;
+  // CS_HLP_ROUTE: RMFPlanner's bookkeeping, rmf/mod.rs:83-94 (the visibility graph and A*
+  // are the host callback d.route_plan)
+  std::map<uint64_t, std::pair<size_t, size_t>> agent_cache;  // id -> (route, next waypoint)
+  std::vector<std::vector<V2>> route_list;
+  std::map<std::array<long long, 4>, size_t> route_plans_by_location;
+  static long long spatial_hash(double v, double res) {  // SpatialHash::new, rmf/mod.rs:70-77
+    const double r = std::round(v / res);
+    if (r != r) return 0;
+    if (r >= 9.2e18) return INT64_MAX;
+    if (r <= -9.2e18) return INT64_MIN;
+    return (long long)r;
+  }
   // highlevel_planners.rs:9 — Option<Vec2f>
   bool get_desired_velocity(const Agent& a, V2* out) {
     switch (d.kind) {
+      case CS_HLP_ROUTE: {  // rmf/mod.rs:197-215
+        auto it = agent_cache.find(a.agent_id);
+        if (it == agent_cache.end()) return false;
+        const std::vector<V2>& route = route_list[it->second.first];
+        size_t wp = it->second.second;
+        V2 dv = {a.position.x - route[wp].x, a.position.y - route[wp].y};
+        if (std::sqrt(dv.x * dv.x + dv.y * dv.y) < (Real)d.route_arrive && route.size() > wp + 1) {
+          wp += 1;
+          it->second.second = wp;
+        }
+        V2 t = {route[wp].x - a.position.x, route[wp].y - a.position.y};
+        const Real n = std::sqrt(t.x * t.x + t.y * t.y);  // normalize(): 0/0 = NaN on the waypoint
+        *out = {t.x / n * (Real)d.route_speed, t.y / n * (Real)d.route_speed};
+        return true;
+      }
       case CS_HLP_CONSTANT:  // lib.rs:403-410
         *out = {(Real)d.vx, (Real)d.vy};
         return true;
@@ -433,9 +462,31 @@ struct HighLevelPlanner {
     if (d.kind == CS_HLP_CALLBACK && d.set_target)
       d.set_target(d.user, a.agent_id, (double)a.position.x, (double)a.position.y,
                    (double)point.x, (double)point.y, (double)tol.x, (double)tol.y);
+    if (d.kind == CS_HLP_ROUTE && d.route_plan) {  // rmf/mod.rs:217-236
+      const double sx = (double)a.position.x, sy = (double)a.position.y;
+      const std::array<long long, 4> key = {spatial_hash(sx, d.route_scale), spatial_hash(sy, d.route_scale),
+                                            spatial_hash((double)point.x, d.route_scale),
+                                            spatial_hash((double)point.y, d.route_scale)};
+      auto it = route_plans_by_location.find(key);
+      if (it != route_plans_by_location.end()) {
+        agent_cache[a.agent_id] = {it->second, 0};
+        return;
+      }
+      std::vector<double> buf(2 * CS_ROUTE_MAX_WAYPOINTS);
+      size_t n = d.route_plan(d.user, sx, sy, (double)point.x, (double)point.y, buf.data(),
+                              CS_ROUTE_MAX_WAYPOINTS);
+      n = std::min<size_t>(n, CS_ROUTE_MAX_WAYPOINTS);
+      if (n == 0) return;  // "Failed to find contiguous path between source and target"
+      std::vector<V2> route(n);
+      for (size_t k = 0; k < n; ++k) route[k] = {(Real)buf[2 * k], (Real)buf[2 * k + 1]};
+      route_plans_by_location[key] = route_list.size();
+      agent_cache[a.agent_id] = {route_list.size(), 0};
+      route_list.push_back(route);
+    }
   }
   void remove_agent_id(uint64_t id) {
     if (d.kind == CS_HLP_CALLBACK && d.remove_agent) d.remove_agent(d.user, id);
+    if (d.kind == CS_HLP_ROUTE) agent_cache.erase(id);  // rmf/mod.rs:239-241
   }
 };
 

@@ -6,13 +6,15 @@ Host-side mirror of the reference trait surface over the C ABI of the HIP engine
 from ._abi import (CS_CFG_DEFAULT, CS_CFG_FORCE_GATHER, CS_CFG_FORCE_TILED)
 from .simulation import (Agent, CrowdGenerator, CrowdSimError, EventListener, HighLevelPlanner,
                          IdParityHighLevelPlan, LocalPlanner, LocationHash2D, MonotonicCrowd,
-                         NoHighLevelPlan, NoLocalPlan, SeededPoissonCrowd, Simulation, SourceSink,
+                         NoHighLevelPlan, NoLocalPlan, RouteFollower, SeededPoissonCrowd, Simulation,
+                         SourceSink,
                          StubHighLevelPlan, Zanlungo)
 
 __all__ = [
     "Agent", "CrowdGenerator", "CrowdSimError", "EventListener", "HighLevelPlanner",
     "IdParityHighLevelPlan", "LocalPlanner", "LocationHash2D", "MonotonicCrowd",
-    "NoHighLevelPlan", "NoLocalPlan", "SeededPoissonCrowd", "Simulation", "SourceSink",
+    "NoHighLevelPlan", "NoLocalPlan", "RouteFollower", "SeededPoissonCrowd", "Simulation",
+    "SourceSink",
     "StubHighLevelPlan", "Zanlungo", "CS_CFG_DEFAULT", "CS_CFG_FORCE_GATHER",
     "CS_CFG_FORCE_TILED",
 ]

@@ -11,7 +11,8 @@ CS_CFG_DEFAULT = 0
 CS_CFG_FORCE_GATHER = 1
 CS_CFG_FORCE_TILED = 2
 
-CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK = 0, 1, 2, 3
+CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK, CS_HLP_ROUTE = 0, 1, 2, 3, 4
+CS_ROUTE_MAX_WAYPOINTS = 1023
 CS_GEN_MONOTONIC, CS_GEN_POISSON_SEEDED, CS_GEN_CALLBACK = 0, 1, 2
 CS_EVENT_SPAWNED, CS_EVENT_DESTROYED = 1, 2
 (CS_K_NEIGHBOUR_FORCE, CS_K_SCAN, CS_K_SCATTER, CS_K_SPAWN, CS_K_HALO, CS_K_COUNT) = range(6)
@@ -49,10 +50,16 @@ HlpRemoveFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)
 GeneratorFn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_double)
 
 
+RoutePlanFn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                          C.POINTER(C.c_double), C.c_size_t)
+
+
 class HlpDesc(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("vx", C.c_double), ("vy", C.c_double),
                 ("velocity", HlpVelocityFn), ("set_target", HlpSetTargetFn),
-                ("remove_agent", HlpRemoveFn), ("user", C.c_void_p)]
+                ("remove_agent", HlpRemoveFn), ("user", C.c_void_p),
+                ("route_plan", RoutePlanFn), ("route_scale", C.c_double),
+                ("route_arrive", C.c_double), ("route_speed", C.c_double)]
 
 
 class SourceSinkDesc(C.Structure):

@@ -26,7 +26,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "crowdstep.h"
@@ -56,6 +58,7 @@ void cs_destroy(cs_engine* e) {
   e->free_arrays(e->buf[1]);
   hipFree(e->pref); hipFree(e->cell_count); hipFree(e->cell_start); hipFree(e->block_totals);
   hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
+  hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_state_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
   hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->spawn_rec_dev);
@@ -192,6 +195,16 @@ uint32_t cs_register_no_local_plan(cs_engine* e) {
   return (uint32_t)e->lp_kinds.size() - 1;
 }
 uint32_t cs_register_hlp(cs_engine* e, const cs_hlp_desc* d) {
+  if (d->kind == CS_HLP_ROUTE) {
+    if (e->tile) {
+      e->error = "route planners are not available on a tile engine";
+      return UINT32_MAX;
+    }
+    if (!d->route_plan || !(d->route_scale > 0.0) || !(d->route_arrive >= 0.0)) {
+      e->error = "route planner: route_plan, route_scale > 0 and route_arrive >= 0 are required";
+      return UINT32_MAX;
+    }
+  }
   e->hlps.push_back(*d);
   return (uint32_t)e->hlps.size() - 1;
 }

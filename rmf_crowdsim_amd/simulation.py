@@ -129,7 +129,8 @@ class HighLevelPlanner:
         fv, fs, fr = _abi.HlpVelocityFn(velocity), _abi.HlpSetTargetFn(set_target), \
             _abi.HlpRemoveFn(remove)
         keep += [fv, fs, fr]
-        return _abi.HlpDesc(_abi.CS_HLP_CALLBACK, 0.0, 0.0, fv, fs, fr, None), keep
+        return _abi.HlpDesc(_abi.CS_HLP_CALLBACK, 0.0, 0.0, fv, fs, fr, None, _abi.RoutePlanFn(),
+                            0.0, 0.0, 0.0), keep
 
     def _register(self, lib, engine):
         desc, keep = self._desc()
@@ -146,7 +147,7 @@ class _DataPlan(HighLevelPlanner):
     def _desc(self):
         return _abi.HlpDesc(self._kind, self.default_vel[0], self.default_vel[1],
                             _abi.HlpVelocityFn(), _abi.HlpSetTargetFn(), _abi.HlpRemoveFn(),
-                            None), []
+                            None, _abi.RoutePlanFn(), 0.0, 0.0, 0.0), []
 
 
 class NoHighLevelPlan(_DataPlan):
@@ -170,6 +171,35 @@ class IdParityHighLevelPlan(_DataPlan):
     def get_desired_velocity(self, agent, time):
         s = -1.0 if agent.agent_id % 2 == 0 else 1.0
         return (s * self.default_vel[0], s * self.default_vel[1])
+
+
+class RouteFollower(HighLevelPlanner):
+    """The follower half of RMFPlanner (rmf/mod.rs:195-242) with the route search left to the
+    host: `plan_route(start, goal)` returns the waypoints of a route (the goal last) or None,
+    the way RMFPlanner::plan_route does with A* over its visibility graph (rmf/mod.rs:160-192).
+    It is called once per set_target whose (start, goal) SpatialHash pair is new
+    (route_plans_by_location, rmf/mod.rs:217-236); following the route, that is
+    get_desired_velocity (unit vector to the current waypoint, next waypoint inside 0.1,
+    rmf/mod.rs:197-215), runs on the device for every agent every step.
+    """
+
+    def __init__(self, plan_route, scale=1.0, arrive=0.1, speed=1.0):
+        self.plan_route = plan_route
+        self.scale, self.arrive, self.speed = float(scale), float(arrive), float(speed)
+
+    def _desc(self):
+        def plan(_user, sx, sy, gx, gy, out, cap):
+            pts = self.plan_route((sx, sy), (gx, gy))
+            if not pts:
+                return 0
+            n = min(len(pts), int(cap))
+            for k in range(n):
+                out[2 * k], out[2 * k + 1] = float(pts[k][0]), float(pts[k][1])
+            return n
+
+        fp = _abi.RoutePlanFn(plan)
+        return _abi.HlpDesc(_abi.CS_HLP_ROUTE, 0.0, 0.0, _abi.HlpVelocityFn(), _abi.HlpSetTargetFn(),
+                            _abi.HlpRemoveFn(), None, fp, self.scale, self.arrive, self.speed), [fp]
 
 
 # ---- source / sink ---------------------------------------------------------

@@ -521,3 +521,60 @@ def test_nearest_neighbours_on_the_device_index():  # location_hash_2d.rs:311-33
         d = np.hypot(cloud[:, 0] - q[0], cloud[:, 1] - q[1])
         assert big.get_nearest_neighbours(7, q) == [int(i) for i in np.argsort(d, kind="stable")[:7]]
     assert len(big.get_nearest_neighbours(6000, (50.0, 50.0))) == 5000
+
+
+# ---- device route follower (CS_HLP_ROUTE; rmf/mod.rs:195-242) ----------------------------------
+def test_route_follower_kat_on_the_device():
+    from test_oracle_reference_kats import run_route_follower_kat
+    run_route_follower_kat(Simulation)
+
+
+@pytest.mark.parametrize("local,steps,flags", [("none", 1100, 0), ("none", 1100, 2), ("zanlungo", 80, 2)])
+def test_route_follower_stream_matches_oracle(local, steps, flags):
+    """Source-sinks whose agents follow host-planned doglegs; the second sink waypoint makes every
+    agent ask for a new route from wherever it stands (route cache keyed by position hash).
+    flags = 2 forces the LDS-tiled kernel (the crowd is small).  The Zanlungo variant stops after
+    80 steps: followers on one line with velocities equal to an ulp give the reference
+    t_i ~ 1e16, and its (p_i + v t) - (p_j + v t) then cancels to exactly (0, 0), whose
+    normalize() is NaN (zanlungo.rs:109-111,156) - DESIGN.md section 5; the engine works with
+    relative positions and stays finite, so the two part ways once that has happened."""
+    from rmf_crowdsim_amd import RouteFollower
+    from test_oracle_reference_kats import DoglegRoutes
+
+    def run(cls):
+        routes = DoglegRoutes()
+        kw = {"flags": flags} if cls is Simulation else {}
+        sim = cls(LocationHash2D(160.0, 160.0, 2.0, (0.0, 0.0)), **kw)
+        lp = NoLocalPlan() if local == "none" else Zanlungo(0.05, 1.0, 0.0, 0.4, 2.0, 0.2)
+        ls = MockEventListener()
+        sim.add_event_listener(ls)
+        hlp = RouteFollower(routes, scale=4.0, arrive=0.1, speed=1.2)
+        for k in range(16):
+            y = 20.0 + 7.5 * k
+            left = k % 2 == 0
+            src = (20.0, y) if left else (140.0, y)
+            mid = (70.0, y + 3.0) if left else (90.0, y - 3.0)
+            dst = (120.0, y) if left else (40.0, y)
+            sim.add_source_sink(SourceSink(src, 1.0, SeededPoissonCrowd(1.5 if local == "none" else 0.3, 40 + k),
+                                           hlp, lp, [mid, dst], False, 2.0))
+        counts = []
+        for _ in range(steps):
+            sim.step(0.1)
+            counts.append((len(sim), sim.last_report["n_spawned"], sim.last_report["n_destroyed"],
+                           sim.last_report["n_waypoint_hits"]))
+        return sim.read_agents(), counts, ls, routes
+
+    a, ca, la, ra = run(Simulation)
+    b, cb, lb, rb = run(OracleSimulation)
+    assert np.isfinite(b["x"]).all() and np.isfinite(a["x"]).all()
+    assert ca == cb and la.added == lb.added and la.removed == lb.removed
+    if local == "none":
+        assert len(a) > 100 and sum(c[2] for c in ca) > 50 and len(ra.calls) > 16
+    else:
+        assert len(a) > 20
+    err = max_rel_err(a, b, 160.0)
+    print(f"route follower ({local}): {len(a)} alive, {len(ra.calls)} routes planned, max |dp|/L = {err:.3e}")
+    assert err <= 1e-4 and (a["next_waypoint"] == b["next_waypoint"]).all()
+    # the same set_target calls missed the route cache on both sides
+    assert [(round(s[0], 3), round(s[1], 3), g) for s, g in ra.calls] == \
+           [(round(s[0], 3), round(s[1], 3), g) for s, g in rb.calls]
