@@ -77,6 +77,9 @@ def main():
                     help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
+    ap.add_argument("--readback", action="store_true",
+                    help="stream a snapshot of all agents to pinned host memory every step (the "
+                         "PCIe-inclusive rate; not the headline value)")
     args = ap.parse_args()
 
     import torch
@@ -171,6 +174,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper.step(0.05, report=False)
+        if args.readback:  # frame k is fetched while step k + 1 runs
+            sim.snapshot(wait=True)
+            sim.request_snapshot()
+    if args.readback:
+        sim.snapshot(wait=True)
     sync_all()
     elapsed = time.perf_counter() - t0
     sim.profile_enable(0)
@@ -237,6 +245,7 @@ def main():
                 (f"~{args.agents} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m "
                  f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
+                "readback": "every step, 32 B/agent to pinned host memory" if args.readback else "none",
                 "n_spawned_last_step": rep.get("n_spawned"), "n_destroyed_last_step": rep.get("n_destroyed"),
                 "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
                 "speed": speed, "kernel": args.kernel,

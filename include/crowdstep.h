@@ -234,6 +234,26 @@ size_t cs_drain_events(cs_engine*, cs_event* out, size_t cap);
 /* Events are queued only while recording is on (default on).  A host without listeners
  * (lib.rs:88 registry empty) turns it off so the queue cannot grow. */
 void cs_event_recording(cs_engine*, int on);
+/* Streaming `agents` view for a renderer / embedder (lib.rs:71 read every frame,
+ * rmf_crowdsim_viz/src/main.rs:112-128).  cs_snapshot_request queues, behind the
+ * steps already queued, a device-side gather of the live agents (global f64
+ * positions) and its copy into pinned host memory on a second stream; it does
+ * not wait, so the next cs_step overlaps the transfer.  Two buffers alternate.
+ * cs_snapshot_acquire hands out the most recent requested snapshot:
+ *   0 = *out/*n/*step_index filled; the memory stays valid until the second
+ *       cs_snapshot_request from now
+ *   1 = nothing was requested, 2 = not complete yet (only with wait == 0),
+ *   3 = device error (cs_last_error)
+ * Agents come in no particular order (cs_read_agents sorts by id).            */
+typedef struct cs_snapshot_record {
+  double x, y;
+  float vx, vy;
+  uint32_t id;
+  uint32_t next_waypoint;
+} cs_snapshot_record;
+int cs_snapshot_request(cs_engine*);
+int cs_snapshot_acquire(cs_engine*, int wait, const cs_snapshot_record** out,
+                        size_t* n, uint64_t* step_index);
 /* SpatialIndex::get_neighbours_in_radius                location_hash_2d.rs:240-258
  * returns the full count; writes min(count, cap) ids in reference cell order
  * (x-major, y-minor) with ascending id inside a cell. */

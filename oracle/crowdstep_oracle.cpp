@@ -568,6 +568,9 @@ struct cs_engine {
   std::unordered_map<uint64_t, uint32_t> correspondence;       // lib.rs:90
   std::vector<std::shared_ptr<LocalPlanner>> lps;
   std::vector<std::shared_ptr<HighLevelPlanner>> hlps;
+  std::vector<cs_snapshot_record> snapshot;
+  uint64_t snapshot_step = 0, steps_done = 0;
+  bool snapshot_valid = false;
   std::mutex planner_lock;  // stands in for the per-planner Mutex (lib.rs:264-268,288-291)
   std::vector<cs_event> events;
   bool record_events = true;
@@ -854,7 +857,34 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
 void cs_remove_source_sink(cs_engine* e, uint32_t handle) { e->source_sinks.erase(handle); }
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
-  return e->step(dt_seconds, report);
+  const int rc = e->step(dt_seconds, report);
+  if (rc == 0) e->steps_done += 1;
+  return rc;
+}
+// the streaming view has nothing to overlap on the CPU: a plain copy of `agents` (lib.rs:71)
+int cs_snapshot_request(cs_engine* e) {
+  e->snapshot.clear();
+  for (uint64_t id : e->order) {
+    const Agent& a = e->agents.at(id);
+    cs_snapshot_record r;
+    r.x = (double)a.position.x;
+    r.y = (double)a.position.y;
+    r.vx = (float)a.velocity.x;
+    r.vy = (float)a.velocity.y;
+    r.id = (uint32_t)id;
+    r.next_waypoint = (uint32_t)a.next_waypoint;
+    e->snapshot.push_back(r);
+  }
+  e->snapshot_step = e->steps_done;
+  e->snapshot_valid = true;
+  return 0;
+}
+int cs_snapshot_acquire(cs_engine* e, int, const cs_snapshot_record** out, size_t* n, uint64_t* step_index) {
+  if (!e->snapshot_valid) return 1;
+  *out = e->snapshot.data();
+  *n = e->snapshot.size();
+  if (step_index) *step_index = e->snapshot_step;
+  return 0;
 }
 int cs_synchronize(cs_engine*) { return 0; }
 

@@ -62,6 +62,15 @@ class HlpDesc(C.Structure):
                 ("route_arrive", C.c_double), ("route_speed", C.c_double)]
 
 
+class SnapshotRecord(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("vx", C.c_float), ("vy", C.c_float),
+                ("id", C.c_uint32), ("next_waypoint", C.c_uint32)]
+
+
+SNAPSHOT_DTYPE = [("x", "<f8"), ("y", "<f8"), ("vx", "<f4"), ("vy", "<f4"), ("id", "<u4"),
+                  ("next_waypoint", "<u4")]
+
+
 class SourceSinkDesc(C.Structure):
     _fields_ = [("source_x", C.c_double), ("source_y", C.c_double), ("radius_sink", C.c_double),
                 ("generator_kind", C.c_uint32), ("rate", C.c_double), ("seed", C.c_uint64),
@@ -110,6 +119,9 @@ SYMBOLS = {
     "cs_synchronize": (C.c_int, [C.c_void_p]),
     "cs_agent_count": (C.c_size_t, [C.c_void_p]),
     "cs_read_agents": (C.c_size_t, [C.c_void_p, C.POINTER(AgentView), C.c_size_t]),
+    "cs_snapshot_request": (C.c_int, [C.c_void_p]),
+    "cs_snapshot_acquire": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(SnapshotRecord)),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "cs_drain_events": (C.c_size_t, [C.c_void_p, C.POINTER(Event), C.c_size_t]),
     "cs_event_recording": (None, [C.c_void_p, C.c_int]),
     "cs_query_radius": (C.c_size_t, [C.c_void_p, C.c_double, C.c_double, C.c_double,

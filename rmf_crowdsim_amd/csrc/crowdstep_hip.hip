@@ -58,6 +58,13 @@ void cs_destroy(cs_engine* e) {
   e->free_arrays(e->buf[1]);
   hipFree(e->pref); hipFree(e->cell_count); hipFree(e->cell_start); hipFree(e->block_totals);
   hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->destroyed); hipFree(e->wp_events);
+  for (auto& sn : e->snap) {
+    if (sn.in_flight) hipEventSynchronize(sn.copied);
+    hipFree(sn.dev); hipHostFree(sn.host); hipFree(sn.count_dev); hipHostFree(sn.count_host);
+    if (sn.gathered) hipEventDestroy(sn.gathered);
+    if (sn.copied) hipEventDestroy(sn.copied);
+  }
+  if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_state_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
@@ -284,7 +291,20 @@ void cs_remove_source_sink(cs_engine* e, uint32_t handle) {
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
   hipSetDevice(e->device);
-  return e->step(dt_seconds, report);
+  const int rc = e->step(dt_seconds, report);
+  if (rc == 0) e->steps_done += 1;
+  return rc;
+}
+
+int cs_snapshot_request(cs_engine* e) {
+  hipSetDevice(e->device);
+  return e->snapshot_request();
+}
+
+int cs_snapshot_acquire(cs_engine* e, int wait, const cs_snapshot_record** out, size_t* n,
+                        uint64_t* step_index) {
+  hipSetDevice(e->device);
+  return e->snapshot_acquire(wait, out, n, step_index);
 }
 
 int cs_synchronize(cs_engine* e) {

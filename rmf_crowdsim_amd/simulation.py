@@ -464,6 +464,31 @@ class Simulation:
                                      out.ctypes.data_as(C.POINTER(C.c_uint64)))
         return [int(i) for i in out[:got]]
 
+    # -- streaming view for renderers (lib.rs:71 read every frame, main.rs:112-128) --
+    def request_snapshot(self):
+        """Queue a copy of the live agents into pinned host memory behind the steps queued so
+        far; returns at once, the next step overlaps the transfer."""
+        if self._lib.cs_snapshot_request(self._engine) != 0:
+            raise self._err()
+
+    def snapshot(self, wait=True):
+        """The most recently requested snapshot as a structured array view (x, y, vx, vy, id,
+        next_waypoint; unordered) and the number of steps it was taken after, or None when it is
+        not complete yet (wait=False) or nothing was requested.  The view is valid until the
+        second request_snapshot() from now."""
+        out = C.POINTER(_abi.SnapshotRecord)()
+        n, step = C.c_size_t(0), C.c_uint64(0)
+        rc = self._lib.cs_snapshot_acquire(self._engine, 1 if wait else 0, C.byref(out), C.byref(n),
+                                           C.byref(step))
+        if rc in (1, 2):
+            return None
+        if rc != 0:
+            raise self._err()
+        if n.value == 0:
+            return np.zeros(0, dtype=_abi.SNAPSHOT_DTYPE), int(step.value)
+        buf = (C.c_char * (n.value * C.sizeof(_abi.SnapshotRecord))).from_address(C.addressof(out.contents))
+        return np.frombuffer(buf, dtype=_abi.SNAPSHOT_DTYPE), int(step.value)
+
     # -- tiles (multi-GPU): halo hooks, see tiles.py --
     def halo_set_buffers(self, direction, send_ptr, recv_ptr, capacity_records):
         if self._lib.cs_halo_set_buffers(self._engine, int(direction), C.c_void_p(send_ptr),

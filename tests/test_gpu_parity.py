@@ -578,3 +578,48 @@ def test_route_follower_stream_matches_oracle(local, steps, flags):
     # the same set_target calls missed the route cache on both sides
     assert [(round(s[0], 3), round(s[1], 3), g) for s, g in ra.calls] == \
            [(round(s[0], 3), round(s[1], 3), g) for s, g in rb.calls]
+
+
+def test_streaming_snapshots_match_read_agents():
+    """cs_snapshot_request / _acquire: a frame per step without waiting for it before the next
+    step is queued; every frame equals what a synchronous read of a twin simulation gives."""
+    def build(cls):
+        sim = cls(LocationHash2D(120.0, 120.0, 2.0, (0.0, 0.0)))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        pts = scenes.jittered_lattice(3000, 0.63, (30.0, 30.0), 0.2, 11)
+        sim.add_agents(pts, IdParityHighLevelPlan((0.0, 0.001)), lp, 2.0)
+        for k in range(10):
+            sim.add_source_sink(SourceSink((10.0, 10.0 + 3.0 * k), 1.0, SeededPoissonCrowd(3.0, 7 + k),
+                                           StubHighLevelPlan((1.3, 0.0)), lp, [(25.0, 10.0 + 3.0 * k)], False, 2.0))
+        return sim
+    fast, twin = build(Simulation), build(Simulation)
+    assert fast.snapshot() is None
+    frames = []
+    for k in range(60):
+        fast.step(0.05, report=False)
+        fast.request_snapshot()
+        got = fast.snapshot(wait=True)
+        frames.append((got[1], np.sort(got[0].copy(), order="id")))
+    for k in range(60):
+        twin.step(0.05)
+        a = twin.read_agents()
+        step, f = frames[k]
+        assert step == k + 1 and len(f) == len(a)
+        assert (f["id"] == a["id"]).all() and (f["next_waypoint"] == a["next_waypoint"]).all()
+        assert np.array_equal(f["x"], a["x"]) and np.array_equal(f["y"], a["y"])
+        assert np.array_equal(f["vx"].astype(np.float64), a["vx"]) and np.array_equal(f["vy"].astype(np.float64), a["vy"])
+    # double buffering: two requests in flight, the older one stays readable until the second next request
+    fast.step(0.05, report=False)
+    fast.request_snapshot()
+    first = fast.snapshot()[0]
+    keep = first.copy()
+    fast.step(0.05, report=False)
+    fast.request_snapshot()
+    assert fast.snapshot(wait=True)[1] == 62
+    assert np.array_equal(first, keep)
+    # the oracle exposes the same calls (plain copies)
+    ora = build(OracleSimulation)
+    ora.step(0.05)
+    ora.request_snapshot()
+    s, step = ora.snapshot()
+    assert step == 1 and len(s) == len(ora)
