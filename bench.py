@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--cell", type=float, default=2.0)
     ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
     ap.add_argument("--kernel", choices=["auto", "tiled", "gather"], default="auto")
-    ap.add_argument("--workload", choices=["uniform", "stream"], default="uniform",
+    ap.add_argument("--workload", choices=["uniform", "stream", "hotspots"], default="uniform",
                     help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
@@ -107,6 +107,7 @@ def main():
     from rmf_crowdsim_amd.tiles import DistributedTiles, default_tiling
     lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
     n_sinks = 0
+    tile_report = {}
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
@@ -140,7 +141,8 @@ def main():
         speed = scenes.WALK_SPEED
     elif world == 1:
         tiling = (1, 1)
-        pts, grid, extent, group = scenes.uniform_crowd(args.agents, seed=7, cell_size=args.cell)
+        crowd = scenes.hotspot_crowd if args.workload == "hotspots" else scenes.uniform_crowd
+        pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
         sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
                          stream=torch.cuda.current_stream().cuda_stream,
                          capacity_hint=args.agents + 1024)
@@ -149,13 +151,21 @@ def main():
         # weak scaling: one crowd of world * agents, cut into spatial tiles, one tile per rank;
         # every rank sees the global add_agents call and keeps the agents of its own cells
         tiling = default_tiling(world)
-        pts, grid, extent, group = scenes.uniform_crowd(args.agents * world, seed=7, cell_size=args.cell)
+        crowd = scenes.hotspot_crowd if args.workload == "hotspots" else scenes.uniform_crowd
+        pts, grid, extent, group = crowd(args.agents * world, seed=7, cell_size=args.cell)
         halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
+        # a clustered crowd gets cuts at the quantiles of its row / column histograms
+        hot = args.workload == "hotspots"
         stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
-                                   density_per_cell=1.5 * scenes.METRIC_DENSITY * args.cell ** 2,
-                                   capacity_hint=int(args.agents * 1.1) + 4096, flags=flags)
+                                   density_per_cell=(3.0 if hot else 1.5) * scenes.METRIC_DENSITY * args.cell ** 2,
+                                   capacity_hint=int(args.agents * (1.5 if hot else 1.1)) + 4096, flags=flags,
+                                   weights=pts if hot else None)
         sim = stepper.sim
-    if args.workload == "uniform":
+        if hot:
+            counts = stepper.layout.tile_counts(pts, LocationHash2D(**grid))
+            tile_report = {"agents_per_tile": counts.reshape(-1).tolist(),
+                           "imbalance_max_over_mean": float(counts.max() / counts.mean())}
+    if args.workload in ("uniform", "hotspots"):
         scenes.add_counterflow(stepper, pts, group, speed, lp, args.eyesight)
         del pts, group
 
@@ -242,6 +252,10 @@ def main():
                              f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
                              f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s")
                 if args.workload == "uniform" else
+                (f"{args.agents} agents/GPU, half uniform background, half in Gaussian hotspots (sigma 5 m, "
+                 f"800 agents each), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
+                 f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s")
+                if args.workload == "hotspots" else
                 (f"~{args.agents} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m "
                  f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
@@ -254,6 +268,7 @@ def main():
                 f"{backend} send/recv",
                 "n_tti_zero": rep["n_tti_zero"], "n_nonfinite": rep["n_nonfinite"],
                 "n_agents_alive": rep["n_agents"],
+                **tile_report,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

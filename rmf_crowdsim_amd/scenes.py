@@ -97,6 +97,50 @@ def uniform_crowd(n, seed=7, density=METRIC_DENSITY, cell_size=2.0, margin=10.0)
     return pts, grid, extent, group
 
 
+def hotspot_crowd(n, seed=7, cell_size=2.0, margin=10.0, sigma=5.0, per_hotspot=800, site=0.45):
+    """BASELINE.json configs[4]: half of the n agents as a uniform
+    background of METRIC_DENSITY / 2, half in Gaussian hotspots (sigma 5 m, `per_hotspot` agents
+    each).  Sites of a fine jittered lattice (spacing `site` > agent radius, so nobody overlaps)
+    are kept with probability density(x) * site^2; exactly the n sites with the smallest
+    u / p survive.  The lattice caps the density at 1 / site^2 = 4.9 agents/m^2: the reference's
+    Zanlungo model leaves the grid within ten steps when neighbours stand 0.32 m apart, even at
+    creeping speed (the f64 oracle does too).  Returns (positions, grid kwargs, extent, group)
+    like uniform_crowd."""
+    bg_density = METRIC_DENSITY / 2.0
+    extent = math.sqrt((n / 2.0) / bg_density)
+    side = int(math.ceil(extent / site))
+    n_hot = max(1, int(round(n / 2.0 / per_hotspot)))
+    rho = np.full((side, side), bg_density, dtype=np.float32)  # [iy, ix]
+    hk = np.arange(n_hot, dtype=np.uint64)
+    hx = (0.1 + 0.8 * uniform01(seed + 101, 2 * hk)) * extent
+    hy = (0.1 + 0.8 * uniform01(seed + 101, 2 * hk + np.uint64(1))) * extent
+    reach = int(math.ceil(4.0 * sigma / site))
+    peak = (n / 2.0 / n_hot) / (2.0 * math.pi * sigma * sigma)
+    for cx, cy in zip(hx, hy):
+        ix0, iy0 = int(cx / site), int(cy / site)
+        xs = np.arange(max(ix0 - reach, 0), min(ix0 + reach + 1, side))
+        ys = np.arange(max(iy0 - reach, 0), min(iy0 + reach + 1, side))
+        gx = np.exp(-(((xs + 0.5) * site - cx) ** 2) / (2.0 * sigma * sigma))
+        gy = np.exp(-(((ys + 0.5) * site - cy) ** 2) / (2.0 * sigma * sigma))
+        rho[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] += (peak * np.outer(gy, gx)).astype(np.float32)
+    p = np.minimum(rho.reshape(-1).astype(np.float64) * site * site, 1.0)
+    k = np.arange(side * side, dtype=np.uint64)
+    with np.errstate(divide="ignore"):
+        key = uniform01(seed + 202, k) / p
+    keep = np.argpartition(key, n - 1)[:n]
+    keep.sort()
+    kk = keep.astype(np.uint64)
+    ix = (kk % np.uint64(side)).astype(np.float64)
+    iy = (kk // np.uint64(side)).astype(np.float64)
+    jx = (uniform01(seed, 2 * kk) * 2.0 - 1.0) * 0.15 * site
+    jy = (uniform01(seed, 2 * kk + np.uint64(1)) * 2.0 - 1.0) * 0.15 * site
+    pts = np.stack([margin + (ix + 0.5) * site + jx, margin + (iy + 0.5) * site + jy], axis=1)
+    cells = int(math.ceil((extent + 2 * margin) / cell_size))
+    grid = dict(width=cells * cell_size, height=cells * cell_size, cell_size=cell_size, offset=(0.0, 0.0))
+    group = ((keep % side) + (keep // side)) % 2
+    return pts, grid, extent, group
+
+
 def add_counterflow(sim, pts, group, speed, local_planner, eyesight, axis=1):
     """Two interleaved streams: checkerboard group 0 walks +axis, group 1 walks -axis.
     Group 0 is added first, so its agents get the smaller ids (and yield, zanlungo.rs:173-198).

@@ -26,17 +26,56 @@ OPPOSITE = {XLO: XHI, XHI: XLO, YLO: YHI, YHI: YLO}
 RECORD = _abi.CS_HALO_RECORD_BYTES
 
 
-class TileLayout:
-    """Even split of the global cell grid.  `x` is the index that location_to_index multiplies
-    by the row stride (location_hash_2d.rs:59); there are (height / cell) x-rows of
-    (width / cell) cells each."""
+def _weighted_edges(hist, parts, min_width):
+    """Cut range(len(hist)) into `parts` runs of about equal weight, each at least `min_width`
+    cells wide (the cumulative histogram's quantiles, pushed apart where needed)."""
+    n = len(hist)
+    cum = np.concatenate([[0.0], np.cumsum(hist, dtype=np.float64)])
+    total = cum[-1]
+    edges = [0]
+    for k in range(1, parts):
+        e = int(np.searchsorted(cum, total * k / parts, side="left"))
+        e = max(e, edges[-1] + min_width)
+        e = min(e, n - (parts - k) * min_width)
+        edges.append(e)
+    edges.append(n)
+    return edges
 
-    def __init__(self, spatial_index, tiles_x, tiles_y):
+
+class TileLayout:
+    """Tensor-product split of the global cell grid: tiles_x runs of rows by tiles_y runs of
+    columns.  `x` is the index that location_to_index multiplies by the row stride
+    (location_hash_2d.rs:59); there are (height / cell) x-rows of (width / cell) cells each.
+    Without `weights` the runs are even.  With `weights` (agent positions, n x 2) the cuts are
+    the quantiles of the per-row and per-column agent histograms, so a clustered crowd
+    (BASELINE.json configs[4]) is spread more evenly; runs stay at least `min_cells` wide."""
+
+    def __init__(self, spatial_index, tiles_x, tiles_y, weights=None, min_cells=2):
         self.cols = int(spatial_index.width / spatial_index.cell_size)   # stride, y cells per row
         self.rows = int(spatial_index.height / spatial_index.cell_size)  # x rows
         self.tiles_x, self.tiles_y = int(tiles_x), int(tiles_y)
-        self.x_edges = [round(k * self.rows / self.tiles_x) for k in range(self.tiles_x + 1)]
-        self.y_edges = [round(k * self.cols / self.tiles_y) for k in range(self.tiles_y + 1)]
+        if weights is None:
+            self.x_edges = [round(k * self.rows / self.tiles_x) for k in range(self.tiles_x + 1)]
+            self.y_edges = [round(k * self.cols / self.tiles_y) for k in range(self.tiles_y + 1)]
+        else:
+            w = np.asarray(weights, dtype=np.float64)
+            off = spatial_index.offset
+            cx = np.clip(np.floor((w[:, 0] - off[0]) / spatial_index.cell_size), 0, self.rows - 1)
+            cy = np.clip(np.floor((w[:, 1] - off[1]) / spatial_index.cell_size), 0, self.cols - 1)
+            self.x_edges = _weighted_edges(np.bincount(cx.astype(np.int64), minlength=self.rows),
+                                           self.tiles_x, int(min_cells))
+            self.y_edges = _weighted_edges(np.bincount(cy.astype(np.int64), minlength=self.cols),
+                                           self.tiles_y, int(min_cells))
+
+    def tile_counts(self, positions, spatial_index):
+        """Agents per tile (tiles_x x tiles_y) for a set of positions: the imbalance report."""
+        w = np.asarray(positions, dtype=np.float64)
+        off = spatial_index.offset
+        cx = np.clip(np.floor((w[:, 0] - off[0]) / spatial_index.cell_size), 0, self.rows - 1)
+        cy = np.clip(np.floor((w[:, 1] - off[1]) / spatial_index.cell_size), 0, self.cols - 1)
+        tx = np.searchsorted(np.asarray(self.x_edges[1:-1]), cx, side="right")
+        ty = np.searchsorted(np.asarray(self.y_edges[1:-1]), cy, side="right")
+        return np.bincount(tx * self.tiles_y + ty, minlength=self.n_tiles).reshape(self.tiles_x, self.tiles_y)
 
     @property
     def n_tiles(self):
@@ -96,10 +135,10 @@ class LocalTileMesh(_TileBase):
     on the shared stream.  Same engine code path as one-rank-per-GPU."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device=0, capacity_records=None,
-                 density_per_cell=16.0, flags=0):
+                 density_per_cell=16.0, flags=0, weights=None):
         import torch
         self.torch = torch
-        self.layout = TileLayout(spatial_index, *tiles)
+        self.layout = TileLayout(spatial_index, *tiles, weights=weights, min_cells=2 * int(halo_cells))
         self.halo_cells = int(halo_cells)
         assert self.layout.min_tile_cells() >= 2 * self.halo_cells, "tiles thinner than two halos"
         dev = torch.device("cuda", device)
@@ -205,11 +244,11 @@ class DistributedTiles(_TileBase):
     """One tile per rank (rank == tile index) under an initialised torch.distributed group."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device, capacity_records=None,
-                 density_per_cell=16.0, capacity_hint=0, flags=0):
+                 density_per_cell=16.0, capacity_hint=0, flags=0, weights=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.layout = TileLayout(spatial_index, *tiles)
+        self.layout = TileLayout(spatial_index, *tiles, weights=weights, min_cells=2 * int(halo_cells))
         assert self.layout.n_tiles == dist.get_world_size(), "one rank per tile"
         assert self.layout.min_tile_cells() >= 2 * int(halo_cells), "tiles thinner than two halos"
         self.index = dist.get_rank()

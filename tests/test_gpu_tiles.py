@@ -77,6 +77,32 @@ def test_creeping_counterflow_across_tiles():
     assert a.tobytes() == b.tobytes()
 
 
+def test_hotspot_crowd_with_weighted_cuts_matches_single_engine():
+    """BASELINE.json configs[4] in miniature: clustered crowd (cells of up to ~45 agents, far more
+    neighbours in sight than a neighbour list holds), tile cuts at the histogram quantiles."""
+    n = 60000
+    pts, grid, extent, group = scenes.hotspot_crowd(n, seed=13, cell_size=2.0, margin=12.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (3, 2), halo_cells=1, density_per_cell=40.0, weights=pts)
+    even = LocalTileMesh(LocationHash2D(**grid), (3, 2), halo_cells=1, density_per_cell=40.0)
+    for t in (single, mesh, even):
+        scenes.add_counterflow(t, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    for k in range(30):
+        for t in (single, mesh, even):
+            t.step(0.05, report=False)
+    single.step(0.05)
+    mesh.step(0.05)
+    even.step(0.05)
+    a, b, c = single.read_agents(), mesh.read_agents(), even.read_agents()
+    assert len(a) == n and a.tobytes() == b.tobytes() == c.tobytes()
+    assert np.isfinite(a["x"]).all() and single.last_report["n_tti_zero"] == 0
+    wc = np.array([len(e) for e in mesh.engines], dtype=np.float64)
+    ec = np.array([len(e) for e in even.engines], dtype=np.float64)
+    print("agents per tile: weighted", wc.astype(int).tolist(), "even", ec.astype(int).tolist())
+    assert wc.max() / wc.mean() < ec.max() / ec.mean()
+
+
 # ---- one rank per tile, two processes sharing the one GPU of the test box ----------------
 def _rank_main(rank, world, port, out_path):
     import os

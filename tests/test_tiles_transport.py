@@ -71,3 +71,20 @@ def test_two_rank_exchange_over_gloo(tiles):
         p.join(120)
         assert p.exitcode == 0
     assert dict(results) == {0: True, 1: True}
+
+
+def test_weighted_cuts_balance_a_clustered_crowd():
+    """BASELINE.json configs[4]: cuts at the quantiles of the row / column histograms."""
+    from rmf_crowdsim_amd import scenes
+    pts, grid, extent, group = scenes.hotspot_crowd(120_000, seed=3)
+    si = LocationHash2D(**grid)
+    even = TileLayout(si, 4, 2)
+    weighted = TileLayout(si, 4, 2, weights=pts, min_cells=4)
+    ce, cw = even.tile_counts(pts, si), weighted.tile_counts(pts, si)
+    assert ce.sum() == cw.sum() == len(pts)
+    assert cw.max() / cw.mean() < ce.max() / ce.mean() and cw.max() / cw.mean() < 1.2
+    assert weighted.x_edges[0] == 0 and weighted.x_edges[-1] == weighted.rows
+    assert min(np.diff(weighted.x_edges)) >= 4 and min(np.diff(weighted.y_edges)) >= 4
+    # nobody overlaps: the lattice spacing exceeds the agent radius
+    cell = np.floor(pts / 0.2).astype(np.int64)
+    assert len(np.unique(cell[:, 0] * 100000 + cell[:, 1])) == len(pts)
