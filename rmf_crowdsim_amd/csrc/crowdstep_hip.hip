@@ -510,6 +510,7 @@ int cs_halo_set_buffers(cs_engine* e, uint32_t dir, void* send_dev, void* recv_d
   e->halo[dir].send = static_cast<HaloRecord*>(send_dev);
   e->halo[dir].recv = static_cast<HaloRecord*>(recv_dev);
   e->halo[dir].cap = (uint32_t)capacity_records;
+  e->halo_counts_clean[dir / 2] = false;
   // room for everything the four neighbours may deliver in one step
   return e->reserve((uint64_t)e->n_slots + 1024);
 }
