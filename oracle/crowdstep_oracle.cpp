@@ -576,6 +576,11 @@ struct cs_engine {
   bool record_events = true;
   std::string error;
   bool gauss_seidel = false;
+  // ordered pairs (i, j) whose membership in i's radius query depends on
+  // whether j's index entry is still the old position or already the new one, i.e. where the
+  // reference's in-loop index update (lib.rs:299) could make it differ from the Jacobi result
+  bool count_shell = false;
+  uint64_t last_shell_crossings = 0;
 
   explicit cs_engine(const cs_grid_desc& g)
       : index((Real)g.width, (Real)g.height, (Real)g.cell_size,
@@ -748,6 +753,31 @@ struct cs_engine {
         }
       }
       update_buffer[agent_id] = StateUpdate{vel, new_pos, true, next_waypoint};
+    }
+    if (count_shell) {
+      std::unordered_map<uint64_t, V2> moved;
+      Real dmax = 0;
+      for (auto& u : deferred_index_updates) {
+        moved[u.first] = u.second;
+        const V2 d = u.second - agents.at(u.first).position;
+        const Real n = std::sqrt(d.x * d.x + d.y * d.y);
+        if (n == n && n > dmax) dmax = n;
+      }
+      last_shell_crossings = 0;
+      for (uint64_t i : order) {
+        const Agent& me = agents.at(i);
+        const Real r = me.eyesight_range;
+        for (uint64_t j : index.neighbours_in_radius(r + dmax, me.position)) {
+          if (j == i) continue;
+          const V2 po = agents.at(j).position - me.position;
+          auto it = moved.find(j);
+          if (it == moved.end()) continue;
+          const V2 pn = it->second - me.position;
+          const bool in_old = std::sqrt(po.x * po.x + po.y * po.y) < r;
+          const bool in_new = std::sqrt(pn.x * pn.x + pn.y * pn.y) < r;
+          if (in_old != in_new) ++last_shell_crossings;
+        }
+      }
     }
     for (auto& u : deferred_index_updates) index.add_or_update(u.first, u.second);
 
@@ -980,5 +1010,9 @@ int oracle_index_add_or_update(cs_engine* e, uint64_t id, double x, double y) {
   return e->index.add_or_update(id, V2{(Real)x, (Real)y}) ? 0 : 1;
 }
 void oracle_index_remove(cs_engine* e, uint64_t id) { e->index.remove_agent(id); }
+// certification of a parity scene (row a2): count, for the steps that follow, the neighbour pairs
+// that sit on the eyesight shell during the step; read the last step's count back
+void oracle_count_shell_crossings(cs_engine* e, int on) { e->count_shell = on != 0; }
+uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; }
 
 }  // extern "C"

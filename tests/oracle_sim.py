@@ -28,6 +28,10 @@ def load_oracle(kind="f64"):
                                                ctypes.c_double, ctypes.c_double]
     lib.oracle_index_remove.restype = None
     lib.oracle_index_remove.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    lib.oracle_count_shell_crossings.restype = None
+    lib.oracle_count_shell_crossings.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.oracle_shell_crossings.restype = ctypes.c_uint64
+    lib.oracle_shell_crossings.argtypes = [ctypes.c_void_p]
     _libs[kind] = lib
     return lib
 
@@ -38,6 +42,15 @@ class OracleSimulation(Simulation):
 
     def _load_library(self):
         return load_oracle(self._kind)
+
+    def count_shell_crossings(self, on=True):
+        """from now on count, per step, the ordered neighbour pairs whose
+        membership would depend on the reference's visiting order."""
+        self._lib.oracle_count_shell_crossings(self._engine, 1 if on else 0)
+
+    @property
+    def shell_crossings(self):
+        return int(self._lib.oracle_shell_crossings(self._engine))
 
 
 class OracleSimulationF32(OracleSimulation):
