@@ -623,3 +623,25 @@ def test_streaming_snapshots_match_read_agents():
     ora.request_snapshot()
     s, step = ora.snapshot()
     assert step == 1 and len(s) == len(ora)
+
+
+def test_three_way_parity_isolates_rounding_from_kernel_errors():
+    """engine (f32, cell-relative) vs the oracle built in f32 (same algorithm,
+    global f32 coordinates) vs the f64 oracle.  If the engine disagreed with the f64 oracle by
+    much more than the f32 oracle does, that would be a kernel bug rather than rounding."""
+    from oracle_sim import OracleSimulationF32
+    n, steps = 8000, 200
+    res = {}
+    for name, cls in (("gpu", Simulation), ("o32", OracleSimulationF32), ("o64", OracleSimulation)):
+        sim, extent = _crowd(cls, n, 2.0, 2.0, scenes.CREEP_SPEED)
+        for _ in range(steps):
+            sim.step(0.05)
+        res[name] = sim.read_agents()
+    L = extent
+    e_gpu_64 = max_rel_err(res["gpu"], res["o64"], L)
+    e_32_64 = max_rel_err(res["o32"], res["o64"], L)
+    e_gpu_32 = max_rel_err(res["gpu"], res["o32"], L)
+    print(f"three-way |dp|/L after {steps} steps: gpu-vs-f64 {e_gpu_64:.2e}, oracle32-vs-f64 {e_32_64:.2e}, "
+          f"gpu-vs-oracle32 {e_gpu_32:.2e}")
+    assert e_gpu_64 <= 1e-4 and e_32_64 <= 1e-4
+    assert e_gpu_64 <= 10.0 * e_32_64 + 1e-7
