@@ -240,7 +240,7 @@ void cs_event_recording(cs_engine*, int on);
  * positions) and its copy into pinned host memory on a second stream; it does
  * not wait, so the next cs_step overlaps the transfer.  Two buffers alternate.
  * cs_snapshot_acquire hands out the most recent requested snapshot:
- *   0 = *out/*n/*step_index filled; the memory stays valid until the second
+ *   0 = out, n and step_index are filled; the memory stays valid until the second
  *       cs_snapshot_request from now
  *   1 = nothing was requested, 2 = not complete yet (only with wait == 0),
  *   3 = device error (cs_last_error)
