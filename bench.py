@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--cell", type=float, default=2.0)
     ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
     ap.add_argument("--kernel", choices=["auto", "tiled", "gather"], default="auto")
-    ap.add_argument("--workload", choices=["uniform", "stream", "hotspots"], default="uniform",
+    ap.add_argument("--workload", choices=["uniform", "stream", "hotspots", "random"], default="uniform",
                     help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
@@ -141,7 +141,7 @@ def main():
         speed = scenes.WALK_SPEED
     elif world == 1:
         tiling = (1, 1)
-        crowd = scenes.hotspot_crowd if args.workload == "hotspots" else scenes.uniform_crowd
+        crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
         pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
         sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
                          stream=torch.cuda.current_stream().cuda_stream,
@@ -151,7 +151,7 @@ def main():
         # weak scaling: one crowd of world * agents, cut into spatial tiles, one tile per rank;
         # every rank sees the global add_agents call and keeps the agents of its own cells
         tiling = default_tiling(world)
-        crowd = scenes.hotspot_crowd if args.workload == "hotspots" else scenes.uniform_crowd
+        crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
         pts, grid, extent, group = crowd(args.agents * world, seed=7, cell_size=args.cell)
         halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
         # a clustered crowd gets cuts at the quantiles of its row / column histograms
@@ -165,7 +165,7 @@ def main():
             counts = stepper.layout.tile_counts(pts, LocationHash2D(**grid))
             tile_report = {"agents_per_tile": counts.reshape(-1).tolist(),
                            "imbalance_max_over_mean": float(counts.max() / counts.mean())}
-    if args.workload in ("uniform", "hotspots"):
+    if args.workload in ("uniform", "hotspots", "random"):
         scenes.add_counterflow(stepper, pts, group, speed, lp, args.eyesight)
         del pts, group
 
@@ -256,6 +256,10 @@ def main():
                  f"800 agents each), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s")
                 if args.workload == "hotspots" else
+                (f"{args.agents} agents/GPU, {scenes.METRIC_DENSITY}/m^2 on a randomly thinned 0.45 m lattice (neighbour "
+                 f"counts scatter like a real crowd's), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
+                 f"eyesight {args.eyesight} m, cell {args.cell} m, dt 0.05 s")
+                if args.workload == "random" else
                 (f"~{args.agents} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m "
                  f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),

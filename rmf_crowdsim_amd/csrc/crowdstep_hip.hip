@@ -68,7 +68,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_state_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->spawn_rec_dev);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -159,6 +159,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
     (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_SPILL_ROWS")) e->tile_spill_rows = atoi(v);
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(TILE_THREADS, std::max(32, atoi(v)));

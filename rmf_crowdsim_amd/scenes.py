@@ -97,7 +97,8 @@ def uniform_crowd(n, seed=7, density=METRIC_DENSITY, cell_size=2.0, margin=10.0)
     return pts, grid, extent, group
 
 
-def hotspot_crowd(n, seed=7, cell_size=2.0, margin=10.0, sigma=5.0, per_hotspot=800, site=0.45):
+def hotspot_crowd(n, seed=7, cell_size=2.0, margin=10.0, sigma=5.0, per_hotspot=800, site=0.45,
+                  hot_fraction=0.5):
     """BASELINE.json configs[4]: half of the n agents as a uniform
     background of METRIC_DENSITY / 2, half in Gaussian hotspots (sigma 5 m, `per_hotspot` agents
     each).  Sites of a fine jittered lattice (spacing `site` > agent radius, so nobody overlaps)
@@ -106,16 +107,16 @@ def hotspot_crowd(n, seed=7, cell_size=2.0, margin=10.0, sigma=5.0, per_hotspot=
     Zanlungo model leaves the grid within ten steps when neighbours stand 0.32 m apart, even at
     creeping speed (the f64 oracle does too).  Returns (positions, grid kwargs, extent, group)
     like uniform_crowd."""
-    bg_density = METRIC_DENSITY / 2.0
-    extent = math.sqrt((n / 2.0) / bg_density)
+    bg_density = METRIC_DENSITY * (1.0 - hot_fraction)
+    extent = math.sqrt(n / METRIC_DENSITY)
     side = int(math.ceil(extent / site))
-    n_hot = max(1, int(round(n / 2.0 / per_hotspot)))
+    n_hot = max(1, int(round(n * hot_fraction / per_hotspot))) if hot_fraction > 0.0 else 0
     rho = np.full((side, side), bg_density, dtype=np.float32)  # [iy, ix]
     hk = np.arange(n_hot, dtype=np.uint64)
     hx = (0.1 + 0.8 * uniform01(seed + 101, 2 * hk)) * extent
     hy = (0.1 + 0.8 * uniform01(seed + 101, 2 * hk + np.uint64(1))) * extent
     reach = int(math.ceil(4.0 * sigma / site))
-    peak = (n / 2.0 / n_hot) / (2.0 * math.pi * sigma * sigma)
+    peak = (n * hot_fraction / max(n_hot, 1)) / (2.0 * math.pi * sigma * sigma)
     for cx, cy in zip(hx, hy):
         ix0, iy0 = int(cx / site), int(cy / site)
         xs = np.arange(max(ix0 - reach, 0), min(ix0 + reach + 1, side))
@@ -139,6 +140,14 @@ def hotspot_crowd(n, seed=7, cell_size=2.0, margin=10.0, sigma=5.0, per_hotspot=
     grid = dict(width=cells * cell_size, height=cells * cell_size, cell_size=cell_size, offset=(0.0, 0.0))
     group = ((keep % side) + (keep // side)) % 2
     return pts, grid, extent, group
+
+
+def random_crowd(n, seed=7, cell_size=2.0, margin=10.0, site=0.45):
+    """METRIC_DENSITY agents/m^2 without the regularity of uniform_crowd: every site of a fine
+    lattice is kept with the same probability (about one in two), so the number of neighbours in
+    sight scatters like in a real crowd (sigma ~ 4 around 31 at eyesight 2 m) instead of sitting
+    at the lattice value."""
+    return hotspot_crowd(n, seed=seed, cell_size=cell_size, margin=margin, site=site, hot_fraction=0.0)
 
 
 def add_counterflow(sim, pts, group, speed, local_planner, eyesight, axis=1):

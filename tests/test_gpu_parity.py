@@ -303,6 +303,39 @@ def test_tiled_and_gather_kernels_agree_bitwise():
     assert outs[0].tobytes() == outs[1].tobytes()
 
 
+@pytest.mark.parametrize("crowd", ["random", "hotspots"])
+def test_tiled_and_gather_kernels_agree_bitwise_when_lists_overflow(crowd, monkeypatch):
+    """Crowds whose neighbour counts scatter: some lanes hold more neighbours than the LDS list
+    (rows spilled to global memory: "random"), some more than list + spilled rows (the wave
+    drains and runs the filter again: hotspot cores, and everywhere with CS_TILE_SPILL_ROWS=0).
+    All forms must give the gather kernel's bits, and the f64 oracle's values."""
+    make = scenes.random_crowd if crowd == "random" else scenes.hotspot_crowd
+    pts, grid, extent, group = make(30000, seed=17, cell_size=2.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    outs = []
+    for flags, spill in ((1, None), (2, None), (2, "0"), (2, "8")):
+        if spill is None:
+            monkeypatch.delenv("CS_TILE_SPILL_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("CS_TILE_SPILL_ROWS", spill)
+        sim = Simulation(LocationHash2D(**grid), flags=flags)
+        scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+        for _ in range(4):
+            sim.step(0.05, report=False)
+        outs.append(sim.read_agents())
+    for o in outs[1:]:
+        assert outs[0].tobytes() == o.tobytes()
+    ora = OracleSimulation(LocationHash2D(**grid))
+    scenes.add_counterflow(ora, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    for _ in range(4):
+        ora.step(0.05)
+    b = ora.read_agents()
+    ok = np.isfinite(b["x"])
+    assert ok.mean() > 0.999 and np.isfinite(outs[0]["x"]).all()
+    dv = np.hypot(outs[0]["vx"] - b["vx"], outs[0]["vy"] - b["vy"])[ok]
+    assert np.quantile(dv, 0.999) <= 1e-4 * max(np.hypot(b["vx"], b["vy"])[ok].max(), scenes.CREEP_SPEED)
+
+
 def test_runs_are_bitwise_reproducible():
     outs = []
     for _ in range(2):

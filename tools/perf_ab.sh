@@ -10,3 +10,4 @@ run() { timeout -k 10 120 python bench.py --steps 200 --warmup 20 --no-cpu-basel
 echo -n "1M e2c2: "; run || exit 1
 echo -n "1M e1c1: "; run --eyesight 1.0 --cell 1.0 || exit 1
 echo -n "1M hotspots: "; run --workload hotspots || exit 1
+echo -n "1M random: "; run --workload random || exit 1
