@@ -16,7 +16,7 @@ ap.add_argument("--agents", type=int, default=1_000_000)
 ap.add_argument("--eyesight", type=float, default=2.0)
 ap.add_argument("--cell", type=float, default=2.0)
 ap.add_argument("--steps", type=int, default=50)
-ap.add_argument("--workload", choices=["uniform", "hotspots"], default="uniform")
+ap.add_argument("--workload", choices=["uniform", "hotspots", "random"], default="uniform")
 args = ap.parse_args()
 
 os.environ["CS_HIPCC_EXTRA"] = "-DCS_PHASE_CLOCKS"
@@ -28,7 +28,7 @@ try:
     from rmf_crowdsim_amd import scenes  # noqa: E402
     from rmf_crowdsim_amd.simulation import IdParityHighLevelPlan, Simulation, Zanlungo  # noqa: E402
 
-    crowd = scenes.hotspot_crowd if args.workload == "hotspots" else scenes.uniform_crowd
+    crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
     pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
     from rmf_crowdsim_amd.simulation import LocationHash2D
     sim = Simulation(LocationHash2D(**grid))
