@@ -216,9 +216,16 @@ class LocalTileMesh(_TileBase):
         return sum(len(sim) for sim in self.engines)
 
 
-def exchange_axis(dist, layout, index, bufs, axis):
+def exchange_axis(dist, layout, index, bufs, axis, op_cache=None):
     """One phase of the exchange for the tile `index` = this rank: post the sends of this axis
-    and the matching receives as one batch (P2P over xGMI with the nccl/RCCL backend)."""
+    and the matching receives as one batch (P2P over xGMI with the nccl/RCCL backend).  With
+    device buffers on nccl the P2POp list never changes; `op_cache` (a dict) keeps it."""
+    if op_cache is not None and axis in op_cache:
+        ops = op_cache[axis]
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+        return
     tx, ty = layout.coords(index)
     ops, staged = [], []
     for d in ((XLO, XHI) if axis == 0 else (YLO, YHI)):
@@ -233,6 +240,8 @@ def exchange_axis(dist, layout, index, bufs, axis):
             send, recv = send.cpu(), host_recv
         ops.append(dist.P2POp(dist.isend, send, peer))
         ops.append(dist.P2POp(dist.irecv, recv, peer))
+    if op_cache is not None and not staged:
+        op_cache[axis] = ops
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
@@ -266,6 +275,7 @@ class DistributedTiles(_TileBase):
             send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
             self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
             self.bufs[d] = (send, recv)
+        self._op_cache = {} if dist.get_backend() == "nccl" else None
         torch.cuda.synchronize(dev)
 
     def add_agents(self, positions, high_level_planner, local_planner, eyesight):
@@ -279,7 +289,7 @@ class DistributedTiles(_TileBase):
         with self.torch.cuda.stream(self.stream):
             for axis in (0, 1):
                 self.sim.halo_pack(axis)
-                exchange_axis(self.dist, self.layout, self.index, self.bufs, axis)
+                exchange_axis(self.dist, self.layout, self.index, self.bufs, axis, self._op_cache)
                 self.sim.halo_unpack(axis)
         if getattr(self, "_has_sinks", False):
             # ids follow the global sink order: OR the per-tile spawn flags (one small all-reduce)

@@ -191,3 +191,37 @@ def test_source_sinks_across_tiles_match_single_engine(tiles):
     a, b = single.read_agents(), mesh.read_agents()
     assert len(a) > 100 and sum(c[2] for c in counts_s) > 100  # agents were born, walked across, and left
     assert a.tobytes() == b.tobytes()
+
+
+def test_full_size_crowd_invariants():
+    """BASELINE.json configs[1] at its full size (1M agents, 2.5 agents/m^2, eyesight 2 m, cell
+    2 m), through properties that need no oracle run: the LDS-tiled and the gather kernel give
+    the same bits, a 4 x 2 tile mesh (configs[2]'s decomposition) gives the same bits as one
+    engine, two runs give the same bits, nobody is lost or duplicated, every agent feels a
+    finite non-zero force."""
+    n = 1_000_000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+
+    ids = {}
+
+    def run(target, steps=3):
+        ids["of_point"] = scenes.add_counterflow(target, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+        for _ in range(steps):
+            target.step(0.05, report=False)
+        return target.read_agents()
+
+    tiled = run(Simulation(LocationHash2D(**grid), flags=2))
+    again = run(Simulation(LocationHash2D(**grid), flags=2))
+    gather = run(Simulation(LocationHash2D(**grid), flags=1))
+    mesh = run(LocalTileMesh(LocationHash2D(**grid), (4, 2), halo_cells=1, density_per_cell=15.0))
+    assert len(tiled) == n and (tiled["id"] == np.arange(n)).all()
+    assert tiled.tobytes() == again.tobytes() == gather.tobytes() == mesh.tobytes()
+    assert np.isfinite(tiled["x"]).all() and np.isfinite(tiled["vx"]).all()
+    force = np.hypot(tiled["vx"], np.abs(tiled["vy"]) - scenes.CREEP_SPEED)
+    assert np.mean(force > 0) > 0.95
+    # nobody moved further than speed * time allows (forces are ~1e-4 m/s here)
+    start = np.empty_like(pts)
+    start[ids["of_point"]] = pts  # read_agents is in ascending id
+    moved = np.hypot(tiled["x"] - start[:, 0], tiled["y"] - start[:, 1])
+    assert moved.max() < 3 * 0.05 * 0.01
