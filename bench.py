@@ -77,6 +77,9 @@ def main():
                     help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
+    ap.add_argument("--planner", choices=["stub", "route"], default="stub",
+                    help="stream workload: constant-velocity stub planners (the reference tests' kind) or "
+                         "device route followers (CS_HLP_ROUTE, straight two-point routes)")
     ap.add_argument("--readback", action="store_true",
                     help="stream a snapshot of all agents to pinned host memory every step (the "
                          "PCIe-inclusive rate; not the headline value)")
@@ -131,8 +134,11 @@ def main():
                                        capacity_hint=int(args.agents * 1.3) + 4096, flags=flags)
             sim = stepper.sim
         plans = {}
+        if args.planner == "route":
+            from rmf_crowdsim_amd import RouteFollower
+            route_hlp = RouteFollower(lambda start, goal: [start, goal], scale=0.25, speed=scenes.WALK_SPEED)
         for src, dst, vel in lanes:
-            hlp = plans.setdefault(vel, StubHighLevelPlan(vel))
+            hlp = route_hlp if args.planner == "route" else plans.setdefault(vel, StubHighLevelPlan(vel))
             stepper.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False,
                                                args.eyesight))
         n_sinks = len(lanes)
@@ -264,6 +270,7 @@ def main():
                  f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
                  f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
                 "readback": "every step, 32 B/agent to pinned host memory" if args.readback else "none",
+                "planner": args.planner,
                 "n_spawned_last_step": rep.get("n_spawned"), "n_destroyed_last_step": rep.get("n_destroyed"),
                 "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
                 "speed": speed, "kernel": args.kernel,

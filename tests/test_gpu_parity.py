@@ -678,3 +678,33 @@ def test_three_way_parity_isolates_rounding_from_kernel_errors():
           f"gpu-vs-oracle32 {e_gpu_32:.2e}")
     assert e_gpu_64 <= 1e-4 and e_32_64 <= 1e-4
     assert e_gpu_64 <= 10.0 * e_32_64 + 1e-7
+
+
+def test_route_follower_streams_run_without_host_sync():
+    """Single-waypoint sinks with a route planner: after a sink's first spawn the spawn kernel
+    writes the agent's route entry itself, so steps need neither the spawn read-back nor any
+    other host work; the result equals stepping with a report every step, and the oracle's."""
+    from rmf_crowdsim_amd import RouteFollower
+    from test_oracle_reference_kats import DoglegRoutes
+
+    def build(cls):
+        routes = DoglegRoutes()
+        sim = cls(LocationHash2D(160.0, 160.0, 2.0, (0.0, 0.0)))
+        hlp = RouteFollower(routes, scale=4.0, arrive=0.1, speed=1.2)
+        for k in range(16):
+            y = 20.0 + 7.5 * k
+            left = k % 2 == 0
+            sim.add_source_sink(SourceSink((20.0, y) if left else (140.0, y), 1.0, SeededPoissonCrowd(1.5, 70 + k),
+                                           hlp, NoLocalPlan(), [(120.0, y) if left else (40.0, y)], False, 2.0))
+        return sim, routes
+
+    (lazy, rl), (eager, re_), (ora, ro) = build(Simulation), build(Simulation), build(OracleSimulation)
+    for k in range(1000):
+        lazy.step(0.1, report=False)
+        eager.step(0.1, report=True)
+        ora.step(0.1)
+    a, b, c = lazy.read_agents(), eager.read_agents(), ora.read_agents()
+    assert len(a) > 300 and a.tobytes() == b.tobytes()
+    assert (a["id"] == c["id"]).all() and max_rel_err(a, c, 160.0) <= 1e-4
+    assert len(rl.calls) == len(re_.calls) == len(ro.calls) == 16  # one plan per sink
+    assert eager.last_report["n_destroyed"] >= 0 and sum(1 for _ in a) > 0
