@@ -328,7 +328,10 @@ class Simulation:
     def _handle(self, planner):
         key = id(planner)
         if key not in self._planner_handles:
-            self._planner_handles[key] = planner._register(self._lib, self._engine)
+            handle = planner._register(self._lib, self._engine)
+            if handle == 0xFFFFFFFF:  # the engine refused the planner (cs_last_error says why)
+                raise self._err()
+            self._planner_handles[key] = handle
             self._planners_alive.append(planner)
         return self._planner_handles[key]
 

@@ -225,3 +225,10 @@ def test_full_size_crowd_invariants():
     start[ids["of_point"]] = pts  # read_agents is in ascending id
     moved = np.hypot(tiled["x"] - start[:, 0], tiled["y"] - start[:, 1])
     assert moved.max() < 3 * 0.05 * 0.01
+
+
+def test_route_planners_are_refused_on_tile_engines():
+    from rmf_crowdsim_amd import CrowdSimError, RouteFollower
+    mesh = LocalTileMesh(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)), (2, 1), halo_cells=1)
+    with pytest.raises(CrowdSimError, match="tile engine"):
+        mesh.add_agents(np.array([[5.0, 5.0]]), RouteFollower(lambda s, g: [s, g]), NoLocalPlan(), 2.0)
