@@ -185,7 +185,10 @@ def main():
         stepper.step(0.05, report=False)
     sim.synchronize()
     sim.profile_reset()
-    sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)  # hipEvents around K4, on its own stream
+    # hipEvents around K4 on the engine's stream; every 4th launch of the timed region, since an
+    # event pair costs the stream ~6 us per step
+    sim.profile_stride(4)
+    sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -287,7 +290,8 @@ def main():
                 "note": "HBM is the nominal bound of a neighbour gather; the kernel is VALU-issue / "
                         "LDS-latency bound at this neighbour count (DESIGN.md section 4)",
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
-                "kernel_ms": k4_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": k4_ms, "kernel_launches_timed": k4["launches"],
+                "algorithmic_bytes_per_launch": alg_bytes,
                 # what actually bounds it: wave64 VALU instructions (PMC, profiles/r01) against the
                 # chip's issue rate of one per 2 clocks per SIMD (1024 SIMDs, 2.4 GHz)
                 "valu_issue_frac": (valu_insts / (k4_ms * 1e-3) / (1024 * 2.4e9 / 2.0))

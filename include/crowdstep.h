@@ -275,6 +275,9 @@ enum {
 /* Per-kernel hipEvent timing: bit k of kernel_mask times kernel CS_K_k (events are
  * recorded on the engine's stream around each launch); 0 turns timing off. */
 void cs_profile_enable(cs_engine*, uint32_t kernel_mask);
+/* Time only every `every`-th launch of an enabled kernel (default 1 = all): an event pair costs
+ * the stream a few microseconds per launch.  cs_profile_read then reports the timed launches. */
+void cs_profile_stride(cs_engine*, uint32_t every);
 /* Sum of durations (ms) and launch count since the last reset. */
 int cs_profile_read(cs_engine*, uint32_t kernel, double* total_ms, uint64_t* launches);
 void cs_profile_reset(cs_engine*);

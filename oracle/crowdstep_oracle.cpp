@@ -963,6 +963,7 @@ size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_id
 }
 
 void cs_profile_enable(cs_engine*, uint32_t) {}
+void cs_profile_stride(cs_engine*, uint32_t) {}
 int cs_profile_read(cs_engine*, uint32_t, double* total_ms, uint64_t* launches) {
   if (total_ms) *total_ms = 0;
   if (launches) *launches = 0;

@@ -129,6 +129,7 @@ SYMBOLS = {
     "cs_query_knn": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                   C.POINTER(C.c_uint64)]),
     "cs_profile_enable": (None, [C.c_void_p, C.c_uint32]),
+    "cs_profile_stride": (None, [C.c_void_p, C.c_uint32]),
     "cs_profile_read": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double),
                                   C.POINTER(C.c_uint64)]),
     "cs_profile_reset": (None, [C.c_void_p]),

@@ -484,6 +484,7 @@ void cs_debug_phase_cycles(cs_engine* e, unsigned long long* out8, int reset) {
 #endif
 
 void cs_profile_enable(cs_engine* e, uint32_t kernel_mask) { e->profiling = kernel_mask; }
+void cs_profile_stride(cs_engine* e, uint32_t every) { e->prof_stride = every ? every : 1u; }
 int cs_profile_read(cs_engine* e, uint32_t kernel, double* total_ms, uint64_t* launches) {
   if (kernel >= CS_K_COUNT) return 2;
   hipSetDevice(e->device);

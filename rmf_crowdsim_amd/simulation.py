@@ -527,6 +527,10 @@ class Simulation:
         """Bit k times kernel CS_K_k with hipEvents on the engine's stream; 0 = off."""
         self._lib.cs_profile_enable(self._engine, int(kernel_mask) & 0xFFFFFFFF)
 
+    def profile_stride(self, every):
+        """Time only every `every`-th launch of the enabled kernels."""
+        self._lib.cs_profile_stride(self._engine, int(every))
+
     def profile_reset(self):
         self._lib.cs_profile_reset(self._engine)
 
