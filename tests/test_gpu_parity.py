@@ -768,3 +768,31 @@ def test_random_configurations_match_oracle_and_each_other(seed):
     print(f"fuzz {seed}: cell {grid['cell_size']} eyesight {eyesight} grid {grid['width']:.0f}x{grid['height']:.0f} "
           f"|dp|/L {dp:.2e} p99.9 |dv|/vmax {np.quantile(dv, 0.999) / vmax:.2e}")
     assert dp <= 1e-4 and np.quantile(dv, 0.999) <= 1e-4 * vmax
+
+
+def test_degenerate_populations():
+    """Empty engine, one agent, agents added between steps, everybody removed: same as the oracle."""
+    def run(cls):
+        sim = cls(LocationHash2D(40.0, 40.0, 2.0, (-20.0, -20.0)))
+        log = []
+        sim.step(0.05)                                   # nobody there
+        log.append((len(sim), sim.last_report["n_agents"]))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        a = sim.add_agents([(0.0, 0.0)], StubHighLevelPlan((0.5, 0.0)), lp, 2.0)
+        sim.step(0.05)                                   # alone: no neighbours, t_i = inf, no force
+        b = sim.add_agents([(1.0, 0.1), (-19.9, -19.9), (19.9, 19.9)], StubHighLevelPlan((-0.5, 0.0)), lp, 2.0)
+        for _ in range(5):
+            sim.step(0.05)
+        log.append((a, b, len(sim)))
+        sim.remove_agents(a[0])
+        sim.step(0.05)
+        mid = sim.read_agents()
+        for i in b:
+            sim.remove_agents(i)
+        sim.step(0.05)
+        log.append((len(sim), len(sim.read_agents())))
+        return log, mid
+    (lg, mg), (lo, mo) = run(Simulation), run(OracleSimulation)
+    assert lg == lo and lg[-1] == (0, 0)
+    assert (mg["id"] == mo["id"]).all() and max_rel_err(mg, mo, 40.0) <= 1e-6
+    assert np.allclose(mg["vx"], mo["vx"], atol=1e-5) and np.allclose(mg["vy"], mo["vy"], atol=1e-5)
