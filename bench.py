@@ -278,7 +278,7 @@ def main():
                 "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
                 "speed": speed, "kernel": args.kernel,
                 "parallelism": "1 GPU" if world == 1 else
-                f"{tiling[0]}x{tiling[1]} spatial tiles, one per GPU, two-phase halo exchange over "
+                f"{tiling[0]}x{tiling[1]} spatial tiles, one per GPU, one halo exchange with the (up to) 8 neighbours over "
                 f"{backend} send/recv",
                 "n_tti_zero": rep["n_tti_zero"], "n_nonfinite": rep["n_nonfinite"],
                 "n_agents_alive": rep["n_agents"],

@@ -284,13 +284,18 @@ void cs_profile_reset(cs_engine*);
 
 /* ---- tiles: halo exchange hooks (multi-GPU, one engine per rank) -------- */
 /* The reference has no counterpart (single process).  Per step and tile:
+ *   cs_halo_pack_all -> move the eight send buffers to the neighbours' recv buffers
+ *   -> cs_halo_unpack_all -> cs_step
+ * or, in two phases with edge buffers only,
  *   cs_halo_pack(0) -> move XLO/XHI send buffers to the neighbours' recv buffers
  *   -> cs_halo_unpack(0) -> cs_halo_pack(1) -> move YLO/YHI -> cs_halo_unpack(1)
  *   -> cs_step.   The transport is the caller's (RCCL send/recv, torch.distributed,
  * hipMemcpyPeer): the engine only fills and drains device buffers, on its stream.
  * In tile mode cs_add_agents takes the GLOBAL position list on every tile (ids are
  * allocated for all of it, agents outside the owned cells are skipped). */
-enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3 };
+enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3,
+       /* the diagonal neighbours, for the one-phase exchange (cs_halo_pack_all) */
+       CS_DIR_XLO_YLO = 4, CS_DIR_XLO_YHI = 5, CS_DIR_XHI_YLO = 6, CS_DIR_XHI_YHI = 7 };
 #define CS_HALO_RECORD_BYTES 32u
 /* Caller-provided device buffers (e.g. torch CUDA tensors) of
  * (capacity_records + 1) * CS_HALO_RECORD_BYTES bytes: record 0 is the header
@@ -302,6 +307,12 @@ int cs_halo_set_buffers(cs_engine*, uint32_t dir, void* send_dev, void* recv_dev
 int cs_halo_pack(cs_engine*, uint32_t axis);
 /* Merge what arrived on one axis into the tile (as owned agents or ghosts, by cell). */
 int cs_halo_unpack(cs_engine*, uint32_t axis);
+/* One-phase form of the same exchange: with buffers for all eight neighbours (edges and
+ * corners) cs_halo_pack_all fills every send buffer in one launch (an agent near a corner goes
+ * to the diagonal tile directly instead of being forwarded), one transport round moves them,
+ * cs_halo_unpack_all merges the eight receive buffers.  Same result as the two-phase form. */
+int cs_halo_pack_all(cs_engine*);
+int cs_halo_unpack_all(cs_engine*);
 /* Source-sinks on tiles: every tile registers ALL source-sinks (same order); agent ids must
  * follow the global sink order (lib.rs:199-254), so Phase A is split.  After the halo exchange:
  *   cs_spawn_probe   flags[s] = 1 iff this tile owns sink s, its generator fired and nobody

@@ -982,6 +982,14 @@ int cs_halo_unpack(cs_engine* e, uint32_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_halo_pack_all(cs_engine* e) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_halo_unpack_all(cs_engine* e) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 size_t cs_spawn_probe(cs_engine* e, double, uint8_t*, size_t) {
   e->error = "oracle has no tiles";
   return SIZE_MAX;

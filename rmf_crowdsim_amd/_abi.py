@@ -18,6 +18,7 @@ CS_EVENT_SPAWNED, CS_EVENT_DESTROYED = 1, 2
 (CS_K_NEIGHBOUR_FORCE, CS_K_SCAN, CS_K_SCATTER, CS_K_SPAWN, CS_K_HALO, CS_K_COUNT) = range(6)
 KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo"]
 CS_DIR_XLO, CS_DIR_XHI, CS_DIR_YLO, CS_DIR_YHI = 0, 1, 2, 3
+CS_DIR_XLO_YLO, CS_DIR_XLO_YHI, CS_DIR_XHI_YLO, CS_DIR_XHI_YHI = 4, 5, 6, 7
 CS_HALO_RECORD_BYTES = 32
 NO_SOURCE_SINK = 0xFFFFFFFF
 
@@ -137,6 +138,8 @@ SYMBOLS = {
                                       C.c_uint64]),
     "cs_halo_pack": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cs_halo_unpack": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "cs_halo_pack_all": (C.c_int, [C.c_void_p]),
+    "cs_halo_unpack_all": (C.c_int, [C.c_void_p]),
     "cs_spawn_probe": (C.c_size_t, [C.c_void_p, C.c_double, C.POINTER(C.c_uint8), C.c_size_t]),
     "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
 }

@@ -505,16 +505,27 @@ void cs_profile_reset(cs_engine* e) {
 int cs_halo_set_buffers(cs_engine* e, uint32_t dir, void* send_dev, void* recv_dev,
                         uint64_t capacity_records) {
   hipSetDevice(e->device);
-  if (!e->tile || dir > 3 || capacity_records == 0 || capacity_records > 0x7FFFFFFFull) {
-    e->error = "halo buffers need a tile engine, a direction 0..3 and a capacity";
+  if (!e->tile || dir > 7 || capacity_records == 0 || capacity_records > 0x7FFFFFFFull) {
+    e->error = "halo buffers need a tile engine, a direction 0..7 and a capacity";
     return 3;
   }
   e->halo[dir].send = static_cast<HaloRecord*>(send_dev);
   e->halo[dir].recv = static_cast<HaloRecord*>(recv_dev);
   e->halo[dir].cap = (uint32_t)capacity_records;
-  e->halo_counts_clean[dir / 2] = false;
+  if (dir < 4) e->halo_counts_clean[dir / 2] = false;
+  e->halo_all_clean = false;
   // room for everything the four neighbours may deliver in one step
   return e->reserve((uint64_t)e->n_slots + 1024);
+}
+
+int cs_halo_pack_all(cs_engine* e) {
+  hipSetDevice(e->device);
+  return e->halo_pack_all();
+}
+
+int cs_halo_unpack_all(cs_engine* e) {
+  hipSetDevice(e->device);
+  return e->halo_unpack_all();
 }
 
 size_t cs_spawn_probe(cs_engine* e, double dt_seconds, uint8_t* flags, size_t cap) {

@@ -506,6 +506,14 @@ class Simulation:
         if self._lib.cs_halo_unpack(self._engine, int(axis)) != 0:
             raise self._err()
 
+    def halo_pack_all(self):
+        if self._lib.cs_halo_pack_all(self._engine) != 0:
+            raise self._err()
+
+    def halo_unpack_all(self):
+        if self._lib.cs_halo_unpack_all(self._engine) != 0:
+            raise self._err()
+
     def spawn_probe(self, dur):
         """Tile engines: which of MY source-sinks would spawn this step (uint8 flag per sink)."""
         dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)

@@ -5,10 +5,12 @@ The global LocationHash2D grid is cut into tiles_x x tiles_y rectangles of whole
 tile engine owns the agents whose cell lies in its rectangle and keeps `halo_cells` ghost
 cells around it.  Per step:
 
-    pack X -> exchange with the X neighbours -> unpack X      (cs_halo_pack / cs_halo_unpack)
-    pack Y -> exchange with the Y neighbours -> unpack Y      (Y carries what arrived in X,
-                                                               so corners reach diagonal tiles)
-    cs_step on every tile
+    pack -> one exchange with the (up to) eight neighbours -> unpack       (cs_halo_pack_all /
+    cs_step on every tile                                                   cs_halo_unpack_all)
+
+(phases=2 selects the older two-phase schedule: pack X -> exchange -> unpack X -> pack Y ->
+exchange -> unpack Y, where Y forwards what arrived in X so that corners reach diagonal tiles;
+same result, twice the transport rounds.)
 
 Two transports move the fixed-capacity device buffers:
     LocalTileMesh      several tiles in ONE process on one GPU (device-to-device copies);
@@ -22,7 +24,14 @@ from . import _abi
 from .simulation import LocationHash2D, Simulation
 
 XLO, XHI, YLO, YHI = _abi.CS_DIR_XLO, _abi.CS_DIR_XHI, _abi.CS_DIR_YLO, _abi.CS_DIR_YHI
-OPPOSITE = {XLO: XHI, XHI: XLO, YLO: YHI, YHI: YLO}
+XLO_YLO, XLO_YHI, XHI_YLO, XHI_YHI = (_abi.CS_DIR_XLO_YLO, _abi.CS_DIR_XLO_YHI, _abi.CS_DIR_XHI_YLO,
+                                      _abi.CS_DIR_XHI_YHI)
+EDGES = (XLO, XHI, YLO, YHI)
+ALL_DIRS = EDGES + (XLO_YLO, XLO_YHI, XHI_YLO, XHI_YHI)
+OPPOSITE = {XLO: XHI, XHI: XLO, YLO: YHI, YHI: YLO, XLO_YLO: XHI_YHI, XHI_YHI: XLO_YLO,
+            XLO_YHI: XHI_YLO, XHI_YLO: XLO_YHI}
+STEP_OF = {XLO: (-1, 0), XHI: (1, 0), YLO: (0, -1), YHI: (0, 1), XLO_YLO: (-1, -1), XLO_YHI: (-1, 1),
+           XHI_YLO: (1, -1), XHI_YHI: (1, 1)}
 RECORD = _abi.CS_HALO_RECORD_BYTES
 
 
@@ -91,7 +100,7 @@ class TileLayout:
         return (self.x_edges[tx], self.x_edges[tx + 1], self.y_edges[ty], self.y_edges[ty + 1])
 
     def neighbour(self, tx, ty, direction):
-        dx, dy = {XLO: (-1, 0), XHI: (1, 0), YLO: (0, -1), YHI: (0, 1)}[direction]
+        dx, dy = STEP_OF[direction]
         nx, ny = tx + dx, ty + dy
         if 0 <= nx < self.tiles_x and 0 <= ny < self.tiles_y:
             return self.index(nx, ny)
@@ -135,9 +144,10 @@ class LocalTileMesh(_TileBase):
     on the shared stream.  Same engine code path as one-rank-per-GPU."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device=0, capacity_records=None,
-                 density_per_cell=16.0, flags=0, weights=None):
+                 density_per_cell=16.0, flags=0, weights=None, phases=1):
         import torch
         self.torch = torch
+        self.phases = int(phases)
         self.layout = TileLayout(spatial_index, *tiles, weights=weights, min_cells=2 * int(halo_cells))
         self.halo_cells = int(halo_cells)
         assert self.layout.min_tile_cells() >= 2 * self.halo_cells, "tiles thinner than two halos"
@@ -153,7 +163,7 @@ class LocalTileMesh(_TileBase):
             tx, ty = self.layout.coords(index)
             cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
             bufs = {}
-            for d in (XLO, XHI, YLO, YHI):
+            for d in (EDGES if self.phases == 2 else ALL_DIRS):
                 if self.layout.neighbour(tx, ty, d) is None:
                     continue
                 send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
@@ -194,9 +204,24 @@ class LocalTileMesh(_TileBase):
         for sim in self.engines:
             sim.halo_unpack(axis)
 
+    def _exchange_all(self):
+        for sim in self.engines:
+            sim.halo_pack_all()
+        with self.torch.cuda.stream(self.stream):
+            for index, bufs in enumerate(self.bufs):
+                tx, ty = self.layout.coords(index)
+                for d, (send, _) in bufs.items():
+                    peer = self.layout.neighbour(tx, ty, d)
+                    self.bufs[peer][OPPOSITE[d]][1].copy_(send, non_blocking=True)
+        for sim in self.engines:
+            sim.halo_unpack_all()
+
     def step(self, dur, report=True):
-        self._exchange(0)
-        self._exchange(1)
+        if self.phases == 2:
+            self._exchange(0)
+            self._exchange(1)
+        else:
+            self._exchange_all()
         if getattr(self, "_has_sinks", False):
             flags = None
             for sim in self.engines:
@@ -249,14 +274,46 @@ def exchange_axis(dist, layout, index, bufs, axis, op_cache=None):
         dev_recv.copy_(host_recv)
 
 
+def exchange_all(dist, layout, index, bufs, op_cache=None):
+    """The one-phase exchange for the tile `index` = this rank: every send and the matching
+    receive (edges and corners) in one batch."""
+    if op_cache is not None and "all" in op_cache:
+        ops = op_cache["all"]
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+        return
+    tx, ty = layout.coords(index)
+    ops, staged = [], []
+    for d in ALL_DIRS:
+        peer = layout.neighbour(tx, ty, d)
+        if peer is None or d not in bufs:
+            continue
+        send, recv = bufs[d]
+        if send.is_cuda and dist.get_backend() == "gloo":
+            host_recv = recv.cpu()
+            staged.append((recv, host_recv))
+            send, recv = send.cpu(), host_recv
+        ops.append(dist.P2POp(dist.isend, send, peer))
+        ops.append(dist.P2POp(dist.irecv, recv, peer))
+    if op_cache is not None and not staged:
+        op_cache["all"] = ops
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+    for dev_recv, host_recv in staged:
+        dev_recv.copy_(host_recv)
+
+
 class DistributedTiles(_TileBase):
     """One tile per rank (rank == tile index) under an initialised torch.distributed group."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device, capacity_records=None,
-                 density_per_cell=16.0, capacity_hint=0, flags=0, weights=None):
+                 density_per_cell=16.0, capacity_hint=0, flags=0, weights=None, phases=1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.phases = int(phases)
         self.layout = TileLayout(spatial_index, *tiles, weights=weights, min_cells=2 * int(halo_cells))
         assert self.layout.n_tiles == dist.get_world_size(), "one rank per tile"
         assert self.layout.min_tile_cells() >= 2 * int(halo_cells), "tiles thinner than two halos"
@@ -269,7 +326,7 @@ class DistributedTiles(_TileBase):
         tx, ty = self.layout.coords(self.index)
         cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
         self.bufs = {}
-        for d in (XLO, XHI, YLO, YHI):
+        for d in (EDGES if self.phases == 2 else ALL_DIRS):
             if self.layout.neighbour(tx, ty, d) is None:
                 continue
             send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
@@ -287,10 +344,15 @@ class DistributedTiles(_TileBase):
 
     def step(self, dur, report=False):
         with self.torch.cuda.stream(self.stream):
-            for axis in (0, 1):
-                self.sim.halo_pack(axis)
-                exchange_axis(self.dist, self.layout, self.index, self.bufs, axis, self._op_cache)
-                self.sim.halo_unpack(axis)
+            if self.phases == 2:
+                for axis in (0, 1):
+                    self.sim.halo_pack(axis)
+                    exchange_axis(self.dist, self.layout, self.index, self.bufs, axis, self._op_cache)
+                    self.sim.halo_unpack(axis)
+            else:
+                self.sim.halo_pack_all()
+                exchange_all(self.dist, self.layout, self.index, self.bufs, self._op_cache)
+                self.sim.halo_unpack_all()
         if getattr(self, "_has_sinks", False):
             # ids follow the global sink order: OR the per-tile spawn flags (one small all-reduce)
             flags = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))

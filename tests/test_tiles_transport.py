@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 from rmf_crowdsim_amd import LocationHash2D
 from rmf_crowdsim_amd.tiles import (OPPOSITE, RECORD, XHI, XLO, YHI, YLO, TileLayout, default_tiling,
-                                    exchange_axis, halo_capacity)
+                                    ALL_DIRS, exchange_all, exchange_axis, halo_capacity)
 
 
 def test_layout_covers_the_grid_without_overlap():
@@ -25,12 +25,52 @@ def test_layout_covers_the_grid_without_overlap():
     assert lay.neighbour(0, 0, XLO) is None and lay.neighbour(0, 0, XHI) == lay.index(1, 0)
     assert lay.neighbour(3, 1, YLO) == lay.index(3, 0) and lay.neighbour(3, 1, YHI) is None
     for t in range(lay.n_tiles):
-        for d in (XLO, XHI, YLO, YHI):
+        for d in ALL_DIRS:  # edges and corners
             peer = lay.neighbour(*lay.coords(t), d)
             if peer is not None:
                 assert lay.neighbour(*lay.coords(peer), OPPOSITE[d]) == t
     assert default_tiling(8) == (4, 2) and default_tiling(4) == (2, 2) and default_tiling(2) == (2, 1)
     assert halo_capacity(lay, 10.0, 1) >= 1024
+
+
+def _worker_all(rank, world, port, tiles, results):
+    """One-phase exchange: every rank posts all its sends and receives (edges and corners) at once."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = TileLayout(LocationHash2D(64.0, 64.0, 2.0, (0.0, 0.0)), *tiles)
+        tx, ty = lay.coords(rank)
+        cap = 8
+        bufs = {}
+        for d in ALL_DIRS:
+            if lay.neighbour(tx, ty, d) is None:
+                continue
+            send = torch.full(((cap + 1) * RECORD,), 16 * rank + d, dtype=torch.uint8)
+            recv = torch.zeros((cap + 1) * RECORD, dtype=torch.uint8)
+            bufs[d] = (send, recv)
+        for _ in range(2):  # twice: buffers are reused every step
+            exchange_all(dist, lay, rank, bufs)
+        ok = True
+        for d, (send, recv) in bufs.items():
+            peer = lay.neighbour(tx, ty, d)
+            ok = ok and bool((recv == 16 * peer + OPPOSITE[d]).all())
+        results[rank] = (ok, len(bufs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_one_phase_exchange_over_gloo():
+    """2 x 2 tiles: every rank has two edge neighbours and one diagonal neighbour."""
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_all, args=(r, 4, 29671, (2, 2), results)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(results) == {r: (True, 3) for r in range(4)}
 
 
 def _worker(rank, world, port, tiles, results):
