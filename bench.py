@@ -103,7 +103,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
-    speed = scenes.CREEP_SPEED if args.speed is None else args.speed
+    # The counter-flow closes the lattice gaps at 2 * speed; once the first pair (of a million)
+    # gets within the model's collision distance its t_i -> 0, the force clamps at 1e15 and the
+    # step fails with "Index out of bounds", on the reference's f64 path as well (DESIGN.md
+    # section 5).  The kernel's cost does not depend on the speed scale (measured: 1e-3, 1e-4 and 1e-5 m/s
+    # give the same time), so long runs creep slower: at most 2.5 cm of closing over the run.
+    if args.speed is None:
+        speed = min(scenes.CREEP_SPEED, 0.25 / (args.steps + args.warmup + 2))
+    else:
+        speed = args.speed
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
 
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
