@@ -113,6 +113,8 @@ def main():
     else:
         speed = args.speed
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
+    if args.workload == "hotspots":
+        flags |= _abi.CS_CFG_DENSE  # more than 64 neighbours in sight in the cores
 
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
     from rmf_crowdsim_amd.tiles import DistributedTiles, default_tiling

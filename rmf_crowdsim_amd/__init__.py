@@ -3,7 +3,7 @@
 Host-side mirror of the reference trait surface over the C ABI of the HIP engine
 (include/crowdstep.h, csrc/crowdstep_hip.hip).  There is no CPU fallback.
 """
-from ._abi import (CS_CFG_DEFAULT, CS_CFG_FORCE_GATHER, CS_CFG_FORCE_TILED)
+from ._abi import (CS_CFG_DEFAULT, CS_CFG_DENSE, CS_CFG_FORCE_GATHER, CS_CFG_FORCE_TILED)
 from .simulation import (Agent, CrowdGenerator, CrowdSimError, EventListener, HighLevelPlanner,
                          IdParityHighLevelPlan, LocalPlanner, LocationHash2D, MonotonicCrowd,
                          NoHighLevelPlan, NoLocalPlan, RouteFollower, SeededPoissonCrowd, Simulation,
@@ -15,6 +15,6 @@ __all__ = [
     "IdParityHighLevelPlan", "LocalPlanner", "LocationHash2D", "MonotonicCrowd",
     "NoHighLevelPlan", "NoLocalPlan", "RouteFollower", "SeededPoissonCrowd", "Simulation",
     "SourceSink",
-    "StubHighLevelPlan", "Zanlungo", "CS_CFG_DEFAULT", "CS_CFG_FORCE_GATHER",
+    "StubHighLevelPlan", "Zanlungo", "CS_CFG_DEFAULT", "CS_CFG_DENSE", "CS_CFG_FORCE_GATHER",
     "CS_CFG_FORCE_TILED",
 ]

@@ -313,7 +313,7 @@ def test_tiled_and_gather_kernels_agree_bitwise_when_lists_overflow(crowd, monke
     pts, grid, extent, group = make(30000, seed=17, cell_size=2.0)
     lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
     outs = []
-    for flags, spill in ((1, None), (2, None), (2, "0"), (2, "8")):
+    for flags, spill in ((1, None), (2, None), (2, "0"), (2, "8"), (2 | 4, None)):  # 4 = CS_CFG_DENSE: 128-entry lists
         if spill is None:
             monkeypatch.delenv("CS_TILE_SPILL_ROWS", raising=False)
         else:
