@@ -326,6 +326,12 @@ int cs_halo_unpack_all(cs_engine*);
  * then cs_step.  Generators must be deterministic across tiles (MONOTONIC, POISSON_SEEDED). */
 size_t cs_spawn_probe(cs_engine*, double dt_seconds, uint8_t* flags, size_t cap);
 int cs_spawn_commit(cs_engine*, const uint8_t* flags, size_t n);
+/* The same two calls with the flags in device memory (one int per sink) and no wait for the
+ * host: the probe is a kernel, the caller all-reduces (max) the device vectors, the commit
+ * kernel hands out the ids from the engine's device-side counter.  For hosts without listeners,
+ * callback planners and per-step reports; the host-side pair above remains for those. */
+int cs_spawn_probe_dev(cs_engine*, double dt_seconds, int* flags_dev, size_t cap);
+int cs_spawn_commit_dev(cs_engine*, const int* flags_dev, size_t n);
 
 #ifdef __cplusplus
 }

@@ -998,6 +998,14 @@ int cs_spawn_commit(cs_engine* e, const uint8_t*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_spawn_probe_dev(cs_engine* e, double, int*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_spawn_commit_dev(cs_engine* e, const int*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 
 // Oracle-only probes used by tests/test_oracle_reference_kats.py to pin the
 // private pieces the reference's own unit tests reach (zanlungo.rs:225-236).

@@ -143,6 +143,8 @@ SYMBOLS = {
     "cs_halo_unpack_all": (C.c_int, [C.c_void_p]),
     "cs_spawn_probe": (C.c_size_t, [C.c_void_p, C.c_double, C.POINTER(C.c_uint8), C.c_size_t]),
     "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
+    "cs_spawn_probe_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]),
+    "cs_spawn_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 

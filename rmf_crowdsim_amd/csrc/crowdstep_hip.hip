@@ -547,6 +547,28 @@ int cs_spawn_commit(cs_engine* e, const uint8_t* flags, size_t n) {
   return e->spawn_commit(flags);
 }
 
+int cs_spawn_probe_dev(cs_engine* e, double dt_seconds, int* flags_dev, size_t cap) {
+  hipSetDevice(e->device);
+  if (!e->tile || cap < e->sinks.size() || !flags_dev) {
+    e->error = "cs_spawn_probe_dev needs a tile engine and room for one flag per source-sink";
+    return 3;
+  }
+  if (e->record_events || e->any_callback_hlp) {
+    e->error = "cs_spawn_probe_dev: listeners and host planners need the host-side cs_spawn_probe";
+    return 3;
+  }
+  return e->spawn_probe_dev(dt_seconds, flags_dev);
+}
+
+int cs_spawn_commit_dev(cs_engine* e, const int* flags_dev, size_t n) {
+  hipSetDevice(e->device);
+  if (!e->tile || n < e->sinks.size() || !flags_dev) {
+    e->error = "cs_spawn_commit_dev needs a tile engine and one flag per source-sink";
+    return 3;
+  }
+  return e->spawn_commit_dev(flags_dev);
+}
+
 int cs_halo_pack(cs_engine* e, uint32_t axis) {
   hipSetDevice(e->device);
   if (!e->tile || axis > 1) {

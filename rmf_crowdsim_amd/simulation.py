@@ -492,6 +492,21 @@ class Simulation:
         buf = (C.c_char * (n.value * C.sizeof(_abi.SnapshotRecord))).from_address(C.addressof(out.contents))
         return np.frombuffer(buf, dtype=_abi.SNAPSHOT_DTYPE), int(step.value)
 
+    def spawn_probe_dev(self, dur, flags_ptr, n):
+        """Tile engines, no host wait: flags (one int32 per sink) go to device memory at flags_ptr."""
+        dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
+        if self._lib.cs_spawn_probe_dev(self._engine, dt, C.c_void_p(flags_ptr), int(n)) != 0:
+            raise self._err()
+
+    def spawn_commit_dev(self, flags_ptr, n):
+        if self._lib.cs_spawn_commit_dev(self._engine, C.c_void_p(flags_ptr), int(n)) != 0:
+            raise self._err()
+
+    @property
+    def host_events_needed(self):
+        """True when spawn / waypoint / destroy events must reach the host (listeners)."""
+        return bool(self._listeners)
+
     # -- tiles (multi-GPU): halo hooks, see tiles.py --
     def halo_set_buffers(self, direction, send_ptr, recv_ptr, capacity_records):
         if self._lib.cs_halo_set_buffers(self._engine, int(direction), C.c_void_p(send_ptr),

@@ -127,6 +127,12 @@ def halo_capacity(layout, density_per_cell, halo_cells, slack=2.0):
     return int(max(1024, slack * density_per_cell * edge * 2 * halo_cells))
 
 
+def _is_data_planner(source_sink):
+    """True when the sink's high-level planner runs on the device without host events."""
+    from .simulation import _DataPlan
+    return isinstance(source_sink.high_level_planner, _DataPlan)
+
+
 class _TileBase:
     def _make_engine(self, spatial_index, layout, index, halo_cells, device, stream, capacity_hint,
                      flags):
@@ -152,6 +158,7 @@ class LocalTileMesh(_TileBase):
         self.halo_cells = int(halo_cells)
         assert self.layout.min_tile_cells() >= 2 * self.halo_cells, "tiles thinner than two halos"
         dev = torch.device("cuda", device)
+        self.bufs_device = dev
         # engines and buffer copies must share ONE real stream: torch's default stream has handle 0,
         # which the engine reads as "create your own", and then nothing orders pack -> copy -> unpack
         self.stream = torch.cuda.Stream(dev)
@@ -184,6 +191,8 @@ class LocalTileMesh(_TileBase):
         for sim in self.engines:  # every tile registers every sink; the owner of the source spawns
             handle = sim.add_source_sink(source_sink)
         self._has_sinks = True
+        self._n_sinks = getattr(self, "_n_sinks", 0) + 1
+        self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
         return handle
 
     def add_event_listener(self, listener):
@@ -223,12 +232,28 @@ class LocalTileMesh(_TileBase):
         else:
             self._exchange_all()
         if getattr(self, "_has_sinks", False):
-            flags = None
-            for sim in self.engines:
-                f = sim.spawn_probe(dur)
-                flags = f if flags is None else (flags | f)
-            for sim in self.engines:
-                sim.spawn_commit(flags)
+            if not report and not self._host_planner and not any(e.host_events_needed for e in self.engines):
+                # nobody on the host listens: flags stay on the device (cs_spawn_probe_dev / _commit_dev)
+                n = self._n_sinks
+                with self.torch.cuda.stream(self.stream):
+                    if getattr(self, "_flag_bufs", None) is None or self._flag_bufs[0].numel() < n:
+                        dev = self.bufs_device
+                        self._flag_bufs = [self.torch.zeros(max(n, 1), dtype=self.torch.int32, device=dev)
+                                           for _ in self.engines]
+                    for sim, f in zip(self.engines, self._flag_bufs):
+                        sim.spawn_probe_dev(dur, f.data_ptr(), n)
+                    total = self._flag_bufs[0]
+                    for f in self._flag_bufs[1:]:
+                        total = self.torch.maximum(total, f)
+                    for sim in self.engines:
+                        sim.spawn_commit_dev(total.data_ptr(), n)
+            else:
+                flags = None
+                for sim in self.engines:
+                    f = sim.spawn_probe(dur)
+                    flags = f if flags is None else (flags | f)
+                for sim in self.engines:
+                    sim.spawn_commit(flags)
         for sim in self.engines:
             sim.step(dur, report=report)
 
@@ -340,6 +365,8 @@ class DistributedTiles(_TileBase):
 
     def add_source_sink(self, source_sink):
         self._has_sinks = True
+        self._n_sinks = getattr(self, "_n_sinks", 0) + 1
+        self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
         return self.sim.add_source_sink(source_sink)
 
     def step(self, dur, report=False):
@@ -355,11 +382,27 @@ class DistributedTiles(_TileBase):
                 self.sim.halo_unpack_all()
         if getattr(self, "_has_sinks", False):
             # ids follow the global sink order: OR the per-tile spawn flags (one small all-reduce)
-            flags = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))
-            if self.dist.get_backend() == "nccl":
-                flags = flags.cuda()
-            self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
-            self.sim.spawn_commit(flags.cpu().numpy().astype(np.uint8))
+            if not report and not self._host_planner and not self.sim.host_events_needed:
+                # flags stay on the device; nothing waits for the host
+                n = self._n_sinks
+                with self.torch.cuda.stream(self.stream):
+                    if getattr(self, "_flags_dev", None) is None or self._flags_dev.numel() < n:
+                        self._flags_dev = self.torch.zeros(max(n, 1), dtype=self.torch.int32,
+                                                           device=self.stream.device)
+                    self.sim.spawn_probe_dev(dur, self._flags_dev.data_ptr(), n)
+                    if self.dist.get_backend() == "nccl":
+                        self.dist.all_reduce(self._flags_dev, op=self.dist.ReduceOp.MAX)
+                    else:  # test transport: gloo moves host memory
+                        host = self._flags_dev.cpu()
+                        self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
+                        self._flags_dev.copy_(host)
+                    self.sim.spawn_commit_dev(self._flags_dev.data_ptr(), n)
+            else:
+                flags = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))
+                if self.dist.get_backend() == "nccl":
+                    flags = flags.cuda()
+                self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
+                self.sim.spawn_commit(flags.cpu().numpy().astype(np.uint8))
         self.sim.step(dur, report=report)
 
     def read_agents(self):

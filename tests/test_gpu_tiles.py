@@ -193,6 +193,54 @@ def test_source_sinks_across_tiles_match_single_engine(tiles):
     assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("tiles", [(2, 2), (3, 1)])
+def test_source_sinks_across_tiles_without_the_host(tiles):
+    """Nobody listens and no report is asked for: the spawn flags stay on the device
+    (cs_spawn_probe_dev / cs_spawn_commit_dev), ids come from the device-side counter and the
+    tiles run fire-and-forget; same bits as the single engine, also when host-side steps (with a
+    report) are mixed in."""
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1)
+    for t in (single, mesh):
+        _sink_scene(t)
+    for k in range(800):
+        with_report = k in (250, 251, 600)  # the host-side spawn path in between
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=with_report)
+        if k in (100, 251, 799):
+            assert len(single) == len(mesh)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and a["id"].max() > 400
+    assert a.tobytes() == b.tobytes()
+    extra = [(30.0, 30.0)]
+    assert single.add_agents(extra, StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0) == \
+        mesh.add_agents(extra, StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0)
+
+
+def test_host_queries_between_halo_exchange_and_step_are_harmless():
+    """Tiles run several steps without the host; a count or read-back that lands between the
+    halo unpack and the step must not lose the records the unpack appended."""
+    n = 6000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=21, cell_size=2.0, margin=30.0)
+    vel = [(0.9, 0.9), (-0.9, 0.6)]
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 2), halo_cells=1)
+    for t in (single, mesh):
+        _populate(t, pts, group, vel, NoLocalPlan(), 2.0)
+    for k in range(120):
+        single.step(0.05, report=False)
+        if k % 7 == 5:
+            mesh._exchange_all()
+            assert sum(len(e) for e in mesh.engines) == n  # refreshes the host-side counts mid-step
+            for e in mesh.engines:
+                e.step(0.05, report=False)
+        else:
+            mesh.step(0.05, report=False)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(b) == n and a.tobytes() == b.tobytes()
+
+
 def test_full_size_crowd_invariants():
     """BASELINE.json configs[1] at its full size (1M agents, 2.5 agents/m^2, eyesight 2 m, cell
     2 m), through properties that need no oracle run: the LDS-tiled and the gather kernel give
