@@ -241,6 +241,53 @@ def test_host_queries_between_halo_exchange_and_step_are_harmless():
     assert len(b) == n and a.tobytes() == b.tobytes()
 
 
+def _rank_sinks(rank, world, port, out_path):
+    import os
+    import pickle
+    import torch.distributed as dist
+    from rmf_crowdsim_amd.tiles import DistributedTiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+        tiles = DistributedTiles(LocationHash2D(**grid), (2, 1), halo_cells=1, device=0)
+        _sink_scene(tiles)
+        for k in range(400):
+            tiles.step(0.05, report=(k in (150, 151)))  # mostly the device-side spawn path
+        mine = tiles.read_agents()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            both = np.concatenate(gathered)
+            with open(out_path, "wb") as f:
+                pickle.dump(both[np.argsort(both["id"], kind="stable")], f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path):
+    """One rank per tile: the spawn flags are all-reduced between the ranks (on the device path
+    through a device tensor), ids follow the global sink order; same bits as one engine."""
+    import pickle
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "sinks.pkl")
+    procs = [ctx.Process(target=_rank_sinks, args=(r, 2, 29723, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    both = pickle.load(open(out, "rb"))
+    single = Simulation(LocationHash2D(60.0, 60.0, 2.0, (0.0, 0.0)))
+    _sink_scene(single)
+    for _ in range(400):
+        single.step(0.05, report=False)
+    a = single.read_agents()
+    assert len(a) > 300 and a.tobytes() == both.tobytes()
+
+
 def test_full_size_crowd_invariants():
     """BASELINE.json configs[1] at its full size (1M agents, 2.5 agents/m^2, eyesight 2 m, cell
     2 m), through properties that need no oracle run: the LDS-tiled and the gather kernel give
