@@ -249,6 +249,29 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
     after_mutation();
     if (rc != 0) throw std::runtime_error(cs_last_error(engine_));
   }
+  // The same step without refreshing `agents` and without waiting for the device (an embedder
+  // that renders from snapshots; listeners still get their events at the next step() / refresh).
+  void step_no_readback(std::chrono::duration<double> dur) {
+    if (cs_step(engine_, dur.count(), nullptr) != 0) throw std::runtime_error(cs_last_error(engine_));
+  }
+  // Streaming `agents` view (rmf_crowdsim_viz/src/main.rs:112-128): request a frame behind the
+  // queued steps, pick it up later; the records stay valid until the second request from now.
+  void request_snapshot() {
+    if (cs_snapshot_request(engine_) != 0) throw std::runtime_error(cs_last_error(engine_));
+  }
+  struct Frame {
+    const cs_snapshot_record* agents = nullptr;
+    std::size_t count = 0;
+    uint64_t step_index = 0;
+    bool ready = false;
+  };
+  Frame snapshot(bool wait = true) {
+    Frame f;
+    int rc = cs_snapshot_acquire(engine_, wait ? 1 : 0, &f.agents, &f.count, &f.step_index);
+    if (rc == 3) throw std::runtime_error(cs_last_error(engine_));
+    f.ready = rc == 0;
+    return f;
+  }
 
  private:
   template <class P>

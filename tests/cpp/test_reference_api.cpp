@@ -89,11 +89,31 @@ static void test_viz_scene() {  // rmf_crowdsim_viz/src/main.rs:64-94
   CHECK(std::isfinite(sim.agents.at(1).position.y));
 }
 
+// streaming view: frames requested behind steps that nobody waits for
+static void test_snapshots() {
+  Simulation sim(LocationHash2D(100.0, 100.0, 2.0, Point{-50.0, -50.0}));
+  auto hlp = std::make_shared<StubHighLevelPlan>(Vec2f{1.0, 0.0});
+  auto lp = std::make_shared<NoLocalPlan>();
+  sim.add_agents({Point{0.0, 0.0}, Point{3.0, 4.0}}, hlp, lp, 2.0);
+  CHECK(!sim.snapshot().ready);
+  for (int k = 0; k < 10; ++k) {
+    sim.step_no_readback(std::chrono::duration<double>(0.1));
+    sim.request_snapshot();
+  }
+  Simulation::Frame f = sim.snapshot();
+  CHECK(f.ready && f.count == 2 && f.step_index == 10);
+  for (std::size_t i = 0; i < f.count; ++i) {
+    const double x0 = f.agents[i].id == 0 ? 0.0 : 3.0;
+    CHECK(std::fabs(f.agents[i].x - (x0 + 1.0)) < 1e-5 && std::fabs(f.agents[i].vx - 1.0f) < 1e-6);
+  }
+}
+
 int main() {
+  test_snapshots();
   test_step_integration();
   test_event_listener_source_sink_api();
   test_index_out_of_bounds_is_an_error();
   test_viz_scene();
-  std::printf("4 passed\n");
+  std::printf("5 passed\n");
   return 0;
 }
