@@ -68,8 +68,46 @@ def stream():
             "final": agents_to_rows(sim.read_agents())}
 
 
+def dogleg(start, goal):
+    """The stand-in for RMFPlanner::plan_route used by the route-follower fixture and tests."""
+    import math
+    mx, my = 0.5 * (start[0] + goal[0]), 0.5 * (start[1] + goal[1])
+    dx, dy = goal[0] - start[0], goal[1] - start[1]
+    n = math.hypot(dx, dy) or 1.0
+    return [start, (mx - 2.0 * dy / n, my + 2.0 * dx / n), goal]
+
+
+def route_scene(sim_cls, **kw):
+    from rmf_crowdsim_amd import RouteFollower
+    sim = sim_cls(LocationHash2D(160.0, 160.0, 2.0, (0.0, 0.0)), **kw)
+    hlp = RouteFollower(dogleg, scale=4.0, arrive=0.1, speed=1.2)
+    for k in range(8):
+        y = 20.0 + 7.5 * k
+        left = k % 2 == 0
+        src = (20.0, y) if left else (140.0, y)
+        mid = (70.0, y + 3.0) if left else (90.0, y - 3.0)
+        dst = (120.0, y) if left else (40.0, y)
+        sim.add_source_sink(SourceSink(src, 1.0, SeededPoissonCrowd(1.5, 40 + k), hlp, NoLocalPlan(), [mid, dst],
+                                       False, 2.0))
+    return sim
+
+
+def route_follower():
+    sim = route_scene(OracleSimulation)
+    counts = []
+    for _ in range(1100):
+        sim.step(0.1)
+        counts.append([len(sim), sim.last_report["n_spawned"], sim.last_report["n_destroyed"],
+                       sim.last_report["n_waypoint_hits"]])
+    return {"scene": "8 source-sinks with two waypoints each, RouteFollower(dogleg, scale 4, arrive 0.1, speed 1.2), "
+                     "NoLocalPlan, dt 0.1, 1100 steps",
+            "columns": ["n_agents", "n_spawned", "n_destroyed", "n_waypoint_hits"], "per_step": counts,
+            "final": agents_to_rows(sim.read_agents())}
+
+
 if __name__ == "__main__":
-    for name, fn in (("viz3_1000_steps", viz3), ("config1_256_agents", config1), ("source_sink_stream", stream)):
+    for name, fn in (("viz3_1000_steps", viz3), ("config1_256_agents", config1), ("source_sink_stream", stream),
+                     ("route_follower", route_follower)):
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(fn(), f)
         print("wrote", name)
