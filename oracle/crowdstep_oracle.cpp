@@ -732,7 +732,10 @@ struct cs_engine {
       // waypoint / sink test on the OLD position (lib.rs:304-336)
       uint64_t next_waypoint = agent.next_waypoint;
       auto corr = correspondence.find(agent_id);
-      if (corr != correspondence.end()) {
+      // An agent whose source-sink was removed (lib.rs:164-168) makes the reference panic here:
+      // `registry[source_sink_id]` on a missing key (lib.rs:307).  The engine (and this oracle)
+      // let such an agent walk on without waypoint tests instead.
+      if (corr != correspondence.end() && source_sinks.count(corr->second)) {
         SourceSink& s = *source_sinks.at(corr->second);
         if (agent.next_waypoint >= s.waypoints.size()) {
           // "Rogue agent": the reference pushes it for removal and then indexes

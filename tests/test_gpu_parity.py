@@ -796,3 +796,40 @@ def test_degenerate_populations():
     assert lg == lo and lg[-1] == (0, 0)
     assert (mg["id"] == mo["id"]).all() and max_rel_err(mg, mo, 40.0) <= 1e-6
     assert np.allclose(mg["vx"], mo["vx"], atol=1e-5) and np.allclose(mg["vy"], mo["vy"], atol=1e-5)
+
+
+def test_custom_generator_and_source_sink_removal():
+    """A host CrowdGenerator (trait object, source_sink.rs:30-33) and remove_source_sink
+    (lib.rs:164-168): agents of a removed sink keep walking but are no longer tested against its
+    waypoints; same behaviour as the oracle."""
+    from rmf_crowdsim_amd import CrowdGenerator
+
+    class EveryThird(CrowdGenerator):
+        def __init__(self):
+            self.calls = 0
+
+        def get_number_to_spawn(self, time_elapsed):
+            self.calls += 1
+            return 2 if self.calls % 3 == 0 else 0
+
+    def run(cls):
+        sim = cls(LocationHash2D(80.0, 80.0, 2.0, (0.0, 0.0)))
+        gens = [EveryThird(), EveryThird()]
+        h0 = sim.add_source_sink(SourceSink((5.0, 10.0), 1.0, gens[0], StubHighLevelPlan((1.5, 0.0)), NoLocalPlan(),
+                                            [(30.0, 10.0)], False, 2.0))
+        sim.add_source_sink(SourceSink((5.0, 20.0), 1.0, gens[1], StubHighLevelPlan((1.5, 0.0)), NoLocalPlan(),
+                                       [(30.0, 20.0)], False, 2.0))
+        trace = []
+        for k in range(260):
+            if k == 120:
+                sim.remove_source_sink(h0)
+            sim.step(0.1)
+            trace.append((len(sim), sim.last_report["n_spawned"], sim.last_report["n_destroyed"]))
+        return trace, sim.read_agents(), [g.calls for g in gens]
+
+    (tg, ag, cg), (to, ao, co) = run(Simulation), run(OracleSimulation)
+    assert tg == to and cg == co
+    assert (ag["id"] == ao["id"]).all() and max_rel_err(ag, ao, 80.0) <= 1e-6
+    # agents of the removed sink walked past their old sink point and were not destroyed
+    assert (ag["y"] == 10.0).sum() > 5 and ag["x"][ag["y"] == 10.0].max() > 31.5
+    assert sum(t[2] for t in tg) > 10
