@@ -833,3 +833,26 @@ def test_custom_generator_and_source_sink_removal():
     # agents of the removed sink walked past their old sink point and were not destroyed
     assert (ag["y"] == 10.0).sum() > 5 and ag["x"][ag["y"] == 10.0].max() > 31.5
     assert sum(t[2] for t in tg) > 10
+
+
+def test_nan_positioned_agent_is_inert_and_stays_in_cell_zero():
+    """location_to_index casts NaN to 0 (location_hash_2d.rs:54-66, Rust's saturating `as usize`):
+    such an agent sits in row / column 0 for ever, never passes a radius filter and never
+    disturbs its neighbours.  Same on the engine and the oracle."""
+    def run(cls):
+        sim = cls(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        ids = sim.add_agents([(1.0, 1.0), (float("nan"), 3.0), (1.6, 1.2), (float("nan"), float("nan"))],
+                             StubHighLevelPlan((0.1, 0.05)), lp, 2.0)
+        q = sim.get_neighbours_in_radius(3.0, (1.0, 1.0))
+        for _ in range(20):
+            sim.step(0.05)
+        return ids, q, sim.read_agents(), sim.last_report
+    (ig, qg, ag, rg), (io, qo, ao, ro) = run(Simulation), run(OracleSimulation)
+    assert ig == io and sorted(qg) == sorted(qo) == [0, 2]
+    assert (ag["id"] == ao["id"]).all() and len(ag) == 4
+    assert np.isnan(ag["x"][1]) and np.isnan(ao["x"][1]) and np.isnan(ag["y"][3]) and np.isnan(ao["y"][3])
+    ok = [0, 2]
+    assert np.allclose(ag["x"][ok], ao["x"][ok], atol=1e-6) and np.allclose(ag["y"][ok], ao["y"][ok], atol=1e-6)
+    assert np.allclose(ag["vx"][ok], ao["vx"][ok], atol=1e-6)
+    assert rg["n_nonfinite"] == ro["n_nonfinite"] == 2
