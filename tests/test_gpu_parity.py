@@ -856,3 +856,28 @@ def test_nan_positioned_agent_is_inert_and_stays_in_cell_zero():
     assert np.allclose(ag["x"][ok], ao["x"][ok], atol=1e-6) and np.allclose(ag["y"][ok], ao["y"][ok], atol=1e-6)
     assert np.allclose(ag["vx"][ok], ao["vx"][ok], atol=1e-6)
     assert rg["n_nonfinite"] == ro["n_nonfinite"] == 2
+
+
+def test_row_stride_aliasing_matches_the_reference_layout():
+    """location_to_index multiplies x by width/cell on both axes (location_hash_2d.rs:59): on a
+    grid that is taller than wide an agent whose y index reaches the stride is stored in the next
+    x row's cell.  Queries then find it from that cell's geometric neighbourhood and not from its
+    own (row a4/a5); the engine stores and searches the same way as the oracle."""
+    def run(cls):
+        sim = cls(LocationHash2D(10.0, 30.0, 1.0, (0.0, 0.0)))  # stride 10, 30 x rows
+        lp = Zanlungo(1.0, 1.0, 0.0, 0.4, 2.0, 0.2)
+        pts = [(2.5, 12.5),   # y index 12 >= stride: flat 32 = cell (3, 2)
+               (3.4, 2.6),    # a regular resident of cell (3, 2)
+               (2.6, 12.9),   # aliased too, next to the first one geometrically
+               (3.6, 3.3), (2.4, 2.2), (6.5, 6.5)]
+        ids = sim.add_agents(pts, IdParityHighLevelPlan((0.05, 0.02)), lp, 1.5)
+        queries = [sim.get_neighbours_in_radius(1.2, p) for p in ((3.4, 2.6), (2.5, 12.5), (2.6, 12.0))]
+        for _ in range(10):
+            sim.step(0.05)
+        return ids, queries, sim.read_agents(), sim.last_report
+    (ig, qg, ag, rg), (io, qo, ao, ro) = run(Simulation), run(OracleSimulation)
+    assert ig == io and [sorted(q) for q in qg] == [sorted(q) for q in qo]
+    assert (ag["id"] == ao["id"]).all()
+    assert np.allclose(ag["x"], ao["x"], atol=2e-6) and np.allclose(ag["y"], ao["y"], atol=2e-6)
+    assert np.allclose(ag["vx"], ao["vx"], atol=1e-6) and np.allclose(ag["vy"], ao["vy"], atol=1e-6)
+    assert rg["n_tti_zero"] == ro["n_tti_zero"]
