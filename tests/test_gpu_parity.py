@@ -863,8 +863,8 @@ def test_row_stride_aliasing_matches_the_reference_layout():
     grid that is taller than wide an agent whose y index reaches the stride is stored in the next
     x row's cell.  Queries then find it from that cell's geometric neighbourhood and not from its
     own (row a4/a5); the engine stores and searches the same way as the oracle."""
-    def run(cls):
-        sim = cls(LocationHash2D(10.0, 30.0, 1.0, (0.0, 0.0)))  # stride 10, 30 x rows
+    def run(cls, **kw):
+        sim = cls(LocationHash2D(10.0, 30.0, 1.0, (0.0, 0.0)), **kw)  # stride 10, 30 x rows
         lp = Zanlungo(1.0, 1.0, 0.0, 0.4, 2.0, 0.2)
         pts = [(2.5, 12.5),   # y index 12 >= stride: flat 32 = cell (3, 2)
                (3.4, 2.6),    # a regular resident of cell (3, 2)
@@ -876,6 +876,8 @@ def test_row_stride_aliasing_matches_the_reference_layout():
             sim.step(0.05)
         return ids, queries, sim.read_agents(), sim.last_report
     (ig, qg, ag, rg), (io, qo, ao, ro) = run(Simulation), run(OracleSimulation)
+    forced = run(Simulation, flags=2)  # the LDS-tiled kernel sends such agents down its gather path
+    assert forced[2].tobytes() == ag.tobytes()
     assert ig == io and [sorted(q) for q in qg] == [sorted(q) for q in qo]
     assert (ag["id"] == ao["id"]).all()
     assert np.allclose(ag["x"], ao["x"], atol=2e-6) and np.allclose(ag["y"], ao["y"], atol=2e-6)
