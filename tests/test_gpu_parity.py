@@ -883,3 +883,29 @@ def test_row_stride_aliasing_matches_the_reference_layout():
     assert np.allclose(ag["x"], ao["x"], atol=2e-6) and np.allclose(ag["y"], ao["y"], atol=2e-6)
     assert np.allclose(ag["vx"], ao["vx"], atol=1e-6) and np.allclose(ag["vy"], ao["vy"], atol=1e-6)
     assert rg["n_tti_zero"] == ro["n_tti_zero"]
+
+
+def test_removals_and_additions_in_the_middle_of_unsynced_stretches():
+    """remove_agents / add_agents while steps are still queued (source-sinks, no listener, no
+    report): the host catches up first; ids and states equal the oracle's."""
+    def run(cls):
+        sim = cls(LocationHash2D(120.0, 120.0, 2.0, (0.0, 0.0)))
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        for k in range(12):
+            y = 10.0 + 2.5 * k
+            left = k % 2 == 0
+            sim.add_source_sink(SourceSink((10.0, y) if left else (110.0, y), 1.0, SeededPoissonCrowd(3.0, 300 + k),
+                                           StubHighLevelPlan((1.3, 0.0) if left else (-1.3, 0.0)), lp,
+                                           [(60.0, y) if left else (62.0, y)], False, 2.0))
+        added = []
+        for k in range(300):
+            sim.step(0.05, report=False)
+            if k in (37, 101, 230):
+                victim = sorted(a.agent_id for a in sim.agents.values())[len(sim) // 2]
+                sim.remove_agents(victim)
+                added += sim.add_agents([(100.0 + 0.01 * k, 100.0)], StubHighLevelPlan((0.0, 0.1)), NoLocalPlan(), 1.0)
+                added.append(victim)
+        return added, sim.read_agents()
+    (xg, ag), (xo, ao) = run(Simulation), run(OracleSimulation)
+    assert xg == xo and len(ag) == len(ao) > 100
+    assert (ag["id"] == ao["id"]).all() and max_rel_err(ag, ao, 120.0) <= 1e-4
