@@ -157,6 +157,9 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
     (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+    (void)hipGetLastError();  // (wide cells: a large staged tile)
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_SPILL_ROWS")) e->tile_spill_rows = atoi(v);
