@@ -68,7 +68,8 @@ typedef struct cs_device_cfg {
 #define CS_CFG_FORCE_GATHER 1u  /* use the direct-gather neighbour kernel only */
 #define CS_CFG_FORCE_TILED 2u   /* use the LDS-tiled neighbour kernel only     */
 #define CS_CFG_DENSE 4u         /* expect more than 64 neighbours in sight somewhere (hotspots):
-                                 * neighbour lists of up to 128 entries (more scratch memory) */
+                                 * neighbour lists of up to 128 entries (more scratch memory);
+                                 * chosen automatically when the MEAN occupancy says so */
 
 /* Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
  *               agent_mass, agent_radius)   local_planners/zanlungo.rs:31-48 */

@@ -35,8 +35,8 @@ def run(n, density, cell, eyesight, flags=0):
 
 if __name__ == "__main__":
     n = 1_000_000
-    if len(sys.argv) == 4:  # one configuration: density cell eyesight
-        run(n, float(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3]))
+    if len(sys.argv) >= 4:  # one configuration: density cell eyesight [engine flags]
+        run(n, float(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
         sys.exit(0)
     for density in (0.1, 0.5, 1.0, 2.5, 4.0):
         run(n, density, 2.0, 2.0)
