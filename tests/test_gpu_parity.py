@@ -909,3 +909,23 @@ def test_removals_and_additions_in_the_middle_of_unsynced_stretches():
     (xg, ag), (xo, ao) = run(Simulation), run(OracleSimulation)
     assert xg == xo and len(ag) == len(ao) > 100
     assert (ag["id"] == ao["id"]).all() and max_rel_err(ag, ao, 120.0) <= 1e-4
+
+
+def test_bands_wider_than_the_builders_lds_prefix():
+    """A grid with more columns than the band builder keeps in LDS (2048): windows come from the
+    quantile scheme with the column prefix in global memory.  Tiled and gather kernels agree."""
+    block = scenes.jittered_lattice(900, 0.63, (0.0, 0.0), 0.2, 5, columns=30)  # 19 m x 19 m of crowd
+    pts = np.concatenate([block + np.array([8.0 + 3.0 * (k % 3), 10.0 + 160.0 * k]) for k in range(32)])
+    grid = dict(width=5200.0, height=5200.0, cell_size=2.0, offset=(0.0, 0.0))  # 2600 columns
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    outs = []
+    for flags in (1, 2):
+        sim = Simulation(LocationHash2D(**grid), flags=flags)
+        sim.add_agents(pts, IdParityHighLevelPlan((0.0005, 0.001)), lp, 2.0)
+        for _ in range(3):
+            sim.step(0.05)
+        assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0
+        outs.append(sim.read_agents())
+    assert len(outs[0]) == len(pts) and outs[0].tobytes() == outs[1].tobytes()
+    speed = np.hypot(outs[0]["vx"], outs[0]["vy"])
+    assert (np.abs(speed - np.hypot(0.0005, 0.001)) > 1e-9).mean() > 0.5  # forces act
