@@ -293,7 +293,11 @@ def test_creeping_counterflow_1000_steps():
     assert err <= 1e-4
 
 
-def test_tiled_and_gather_kernels_agree_bitwise():
+@pytest.mark.parametrize("rows", ["2", "1", "3"])
+def test_tiled_and_gather_kernels_agree_bitwise(rows, monkeypatch):
+    """rows = owned rows per workgroup of the tiled kernel (CS_TILE_ROWS): 2-row band windows (the
+    default), 1-row strips cut at agent granularity, 3-row windows."""
+    monkeypatch.setenv("CS_TILE_ROWS", rows)
     outs = []
     for flags in (1, 2):
         s, _ = _crowd(Simulation, 30000, 1.0, 2.0, scenes.WALK_SPEED, flags=flags)
