@@ -63,6 +63,30 @@ def cpu_baseline(agents, cell, eyesight, speed, budget_s=15.0):
     }
 
 
+def cpu_baseline_openmp(agents, cell, eyesight, speed, budget_s=8.0):
+    """What a good CPU does with the same arithmetic (not the reference's shape): the oracle's
+    Zanlungo on cell-sorted arrays, the agent loop spread over the host cores with OpenMP
+    (oracle_fast_steps; bit-identical to the oracle, tests/test_oracle_reference_kats.py)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_sim import fast_steps
+    from rmf_crowdsim_amd import scenes
+    n = min(agents, 1_000_000)
+    threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell)
+    pref = np.zeros((n, 2))
+    pref[:, 1] = np.where(group == 0, speed, -speed)
+    xy, vel, _ = fast_steps(pts, pref, scenes.METRIC_ZANLUNGO, eyesight, grid, 0.05, 1, threads=threads)
+    xy, vel, probe = fast_steps(xy, pref, scenes.METRIC_ZANLUNGO, eyesight, grid, 0.05, 1, threads=threads, vel=vel)
+    steps = int(max(1, min(50, budget_s / max(probe, 1e-3))))
+    xy, vel, sec = fast_steps(xy, pref, scenes.METRIC_ZANLUNGO, eyesight, grid, 0.05, steps, threads=threads, vel=vel)
+    return {
+        "value": n * steps / sec, "unit": "agent-steps/s", "cores": threads, "kind": "port, cell-sorted + OpenMP",
+        "sample": f"{n} agents x {steps} steps of the same scene, the oracle's f64 arithmetic on cell-sorted "
+                  f"arrays, {threads} threads, {sec:.1f} s",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +334,9 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.agents, args.cell, args.eyesight, speed)
+            if args.workload == "uniform":
+                # a second, stronger CPU number (not the reference's shape), for orientation
+                out["cpu_baseline_openmp"] = cpu_baseline_openmp(args.agents, args.cell, args.eyesight, speed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

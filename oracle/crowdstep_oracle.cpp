@@ -44,6 +44,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <limits>
 #include <map>
 #include <memory>
@@ -1034,5 +1038,114 @@ void oracle_index_remove(cs_engine* e, uint64_t id) { e->index.remove_agent(id);
 // that sit on the eyesight shell during the step; read the last step's count back
 void oracle_count_shell_crossings(cs_engine* e, int on) { e->count_shell = on != 0; }
 uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; }
+
+// ---------------------------------------------------------------------------
+// "What a good CPU does" (SURVEY.md section 8d): the same canonical step with the same Zanlungo
+// arithmetic (the methods above), but on cell-sorted arrays instead of the reference's hash
+// maps, and with the agent loop spread over threads (OpenMP).  NOT the reference's shape: bench.py
+// reports it beside the reference-shaped port, clearly labelled.  Crowd of agents with fixed
+// preferred velocities (the bench scene), no source-sinks.  Positions are updated in place;
+// returns the seconds spent in the step loop, or a negative value if an agent left the grid.
+// ---------------------------------------------------------------------------
+double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
+                         double force_distance, double agent_mass, double agent_radius, double eyesight,
+                         double width, double height, double cell_size, double off_x, double off_y,
+                         double dt_seconds, uint32_t steps, int threads) {
+  Zanlungo lp;
+  lp.agent_scale = (Real)agent_scale;
+  lp.obstacle_scale = Real(1);
+  lp.reaction_time = Real(0);
+  lp.force_distance = (Real)force_distance;
+  lp.agent_mass = (Real)agent_mass;
+  lp.agent_radius = (Real)agent_radius;
+  const uint64_t nx = (uint64_t)(width / cell_size), n_rows = (uint64_t)(height / cell_size);
+  const uint64_t ncells = nx * n_rows;
+  std::vector<Agent> cur(n), nxt(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    Agent& a = cur[i];
+    a = Agent{};
+    a.agent_id = i;
+    a.position = {(Real)xy[2 * i], (Real)xy[2 * i + 1]};
+    a.velocity = {(Real)vel_xy[2 * i], (Real)vel_xy[2 * i + 1]};
+    a.eyesight_range = (Real)eyesight;
+  }
+  std::vector<uint32_t> cell_of(n), start(ncells + 1), order(n);
+  bool failed = false;
+  const auto t0 = std::chrono::steady_clock::now();
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  for (uint32_t s = 0; s < steps && !failed; ++s) {
+    // cells in the reference's layout (x_idx * nx + y_idx); members in ascending id
+    std::fill(start.begin(), start.end(), 0u);
+    for (uint64_t i = 0; i < n; ++i) {
+      const double fx = ((double)cur[i].position.x - off_x) / cell_size, fy = ((double)cur[i].position.y - off_y) / cell_size;
+      const uint64_t cx = fx > 0 ? (uint64_t)fx : 0, cy = fy > 0 ? (uint64_t)fy : 0;
+      const uint64_t flat = cx * nx + cy;
+      if (flat >= ncells) {
+        failed = true;
+        break;
+      }
+      cell_of[i] = (uint32_t)flat;
+      start[flat + 1] += 1;
+    }
+    if (failed) break;
+    for (uint64_t c = 0; c < ncells; ++c) start[c + 1] += start[c];
+    {
+      std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+      for (uint64_t i = 0; i < n; ++i) order[fill[cell_of[i]]++] = (uint32_t)i;  // ids ascending inside a cell
+    }
+    const Real dt = (Real)dt_seconds;
+#pragma omp parallel
+    {
+      std::vector<const Agent*> nearby;
+#pragma omp for schedule(dynamic, 256)
+      for (long long k = 0; k < (long long)n; ++k) {
+        const uint32_t i = order[k];  // walk the agents cell by cell: neighbours stay in cache
+        Agent me = cur[i];
+        me.preferred_vel = {(Real)pref_xy[2 * i], (Real)pref_xy[2 * i + 1]};
+        const Real r = me.eyesight_range;
+        const long long lx = (long long)std::floor(((double)me.position.x - (double)r - off_x) / cell_size);
+        const long long hx = (long long)std::floor(((double)me.position.x + (double)r - off_x) / cell_size);
+        const long long ly = (long long)std::floor(((double)me.position.y - (double)r - off_y) / cell_size);
+        const long long hy = (long long)std::floor(((double)me.position.y + (double)r - off_y) / cell_size);
+        nearby.clear();
+        for (long long x = lx; x <= hx; ++x)
+          for (long long y = ly; y <= hy; ++y) {
+            if (x < 0 || y < 0) continue;
+            const unsigned long long flat = (unsigned long long)x * nx + (unsigned long long)y;
+            if (flat >= ncells) continue;
+            for (uint32_t q = start[flat]; q < start[flat + 1]; ++q) {
+              const Agent& o = cur[order[q]];
+              if (o.agent_id == me.agent_id) continue;
+              if (norm(o.position - me.position) < r) nearby.push_back(&o);
+            }
+          }
+        Real t_i = kInf;
+        for (const Agent* o : nearby) {
+          const Real t = lp.time_to_collision(o->velocity - me.velocity, o->position - me.position);
+          if (t < t_i) t_i = t;
+        }
+        V2 force = {Real(0), Real(0)};
+        if (t_i != kInf)
+          for (const Agent* o : nearby) force = force + lp.compute_agent_force(me, *o, t_i);
+        const V2 vel = me.preferred_vel + force * (Real(1) / lp.agent_mass);
+        Agent out = cur[i];
+        out.position = me.position + vel * dt;
+        out.velocity = vel;
+        nxt[i] = out;
+      }
+    }
+    cur.swap(nxt);
+  }
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (uint64_t i = 0; i < n; ++i) {
+    xy[2 * i] = (double)cur[i].position.x;
+    xy[2 * i + 1] = (double)cur[i].position.y;
+    vel_xy[2 * i] = (double)cur[i].velocity.x;
+    vel_xy[2 * i + 1] = (double)cur[i].velocity.y;
+  }
+  return failed ? -1.0 : el;
+}
 
 }  // extern "C"

@@ -32,6 +32,9 @@ def load_oracle(kind="f64"):
     lib.oracle_count_shell_crossings.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.oracle_shell_crossings.restype = ctypes.c_uint64
     lib.oracle_shell_crossings.argtypes = [ctypes.c_void_p]
+    lib.oracle_fast_steps.restype = ctypes.c_double
+    lib.oracle_fast_steps.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
+                                      [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int])
     _libs[kind] = lib
     return lib
 
@@ -55,3 +58,19 @@ class OracleSimulation(Simulation):
 
 class OracleSimulationF32(OracleSimulation):
     _kind = "f32"
+
+
+def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=None):
+    """The OpenMP / cell-sorted CPU baseline (oracle_fast_steps): same arithmetic as the oracle,
+    not the reference's data structures.  Returns (positions, velocities, seconds)."""
+    import numpy as np
+    lib = load_oracle("f64")
+    xy = np.ascontiguousarray(pts, dtype=np.float64).copy()
+    v = np.zeros_like(xy) if vel is None else np.ascontiguousarray(vel, dtype=np.float64).copy()
+    pv = np.ascontiguousarray(pref, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    A, _, _, D, m, R = zanlungo
+    sec = lib.oracle_fast_steps(len(xy), xy.ctypes.data_as(dp), v.ctypes.data_as(dp), pv.ctypes.data_as(dp),
+                                A, D, m, R, eyesight, grid["width"], grid["height"], grid["cell_size"],
+                                grid["offset"][0], grid["offset"][1], dt, steps, threads)
+    return xy, v, sec

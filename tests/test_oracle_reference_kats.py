@@ -344,3 +344,26 @@ def test_reference_visiting_order_does_not_matter_in_the_bench_scene(monkeypatch
     ok = np.isfinite(jac["x"]) & np.isfinite(gs["x"])  # the model's own NaN agents aside
     err = max(np.abs(jac["x"] - gs["x"])[ok].max(), np.abs(jac["y"] - gs["y"])[ok].max()) / 60.0
     assert ok.mean() > 0.99 and 0.0 < err < 1e-4
+
+
+def test_openmp_baseline_reproduces_the_oracle_bit_for_bit():
+    """bench.py's second CPU column (cell-sorted arrays, OpenMP) runs the oracle's own Zanlungo
+    arithmetic in the oracle's order: identical results, on one thread and on several."""
+    from oracle_sim import fast_steps
+    from rmf_crowdsim_amd import scenes
+    n = 3000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=11, cell_size=2.0)
+    sim = OracleSimulation(LocationHash2D(**grid))
+    ids = scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+    for _ in range(12):
+        sim.step(0.05)
+    a = sim.read_agents()
+    # the baseline numbers agents in array order: feed it the points in id order
+    order = np.argsort(ids)
+    pref = np.zeros((n, 2))
+    pref[:, 1] = np.where(group[order] == 0, scenes.CREEP_SPEED, -scenes.CREEP_SPEED)
+    for threads in (1, 4):
+        xy, vel, sec = fast_steps(pts[order], pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, 12, threads=threads)
+        assert sec > 0
+        assert np.array_equal(xy[:, 0], a["x"]) and np.array_equal(xy[:, 1], a["y"])
+        assert np.array_equal(vel[:, 0], a["vx"]) and np.array_equal(vel[:, 1], a["vy"])
