@@ -20,6 +20,9 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # IEEE behaviour the Zanlungo NaN/inf semantics rely on (DESIGN.md "Numerics")
     "-ffp-contract=off", "-fno-fast-math",
+    # measured on the step kernel (3 runs each, 1M agents): 168.9 -> 164.4 us; scheduling only,
+    # no effect on the arithmetic
+    "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fno-unroll-loops",
     "-Wall", "-Wno-unused-function", "-Wno-unused-value",
 ]
 
