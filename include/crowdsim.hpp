@@ -231,7 +231,9 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
     d.loop_forever = s->loop_forever ? 1 : 0;
     d.agent_eyesight_range = s->agent_eyesight_range;
     sinks_.push_back(s);
-    return cs_add_source_sink(engine_, &d);
+    const uint32_t sink = cs_add_source_sink(engine_, &d);
+    if (sink == UINT32_MAX) throw std::runtime_error(cs_last_error(engine_));
+    return sink;
   }
   void remove_source_sink(std::size_t id) { cs_remove_source_sink(engine_, (uint32_t)id); }  // lib.rs:164
   std::size_t add_event_listener(std::shared_ptr<EventListener> l) {                        // lib.rs:171

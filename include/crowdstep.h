@@ -217,7 +217,10 @@ int cs_add_agents(cs_engine*, const double* xy, size_t n, uint32_t hlp,
 /* Simulation::remove_agents (unknown id: returns Err instead of panicking)
  *                                                               lib.rs:176-192 */
 int cs_remove_agent(cs_engine*, uint64_t id);
-/* Simulation::add_source_sink / remove_source_sink              lib.rs:159-168 */
+/* Simulation::add_source_sink / remove_source_sink              lib.rs:159-168
+ * Returns the handle, or UINT32_MAX (cs_last_error says why).  On a tile engine a sink whose
+ * planner is CS_HLP_ROUTE must have exactly one waypoint; its route is planned here (route_plan
+ * is called once per tile, in registration order) so that every tile numbers routes alike. */
 uint32_t cs_add_source_sink(cs_engine*, const cs_source_sink_desc*);
 void cs_remove_source_sink(cs_engine*, uint32_t handle);
 
@@ -299,7 +302,7 @@ void cs_profile_reset(cs_engine*);
 enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3,
        /* the diagonal neighbours, for the one-phase exchange (cs_halo_pack_all) */
        CS_DIR_XLO_YLO = 4, CS_DIR_XLO_YHI = 5, CS_DIR_XHI_YLO = 6, CS_DIR_XHI_YHI = 7 };
-#define CS_HALO_RECORD_BYTES 32u
+#define CS_HALO_RECORD_BYTES 40u
 /* Caller-provided device buffers (e.g. torch CUDA tensors) of
  * (capacity_records + 1) * CS_HALO_RECORD_BYTES bytes: record 0 is the header
  * (word 0 = record count).  A direction without a neighbour tile gets no buffers. */

@@ -20,7 +20,7 @@ CS_EVENT_SPAWNED, CS_EVENT_DESTROYED = 1, 2
 KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo"]
 CS_DIR_XLO, CS_DIR_XHI, CS_DIR_YLO, CS_DIR_YHI = 0, 1, 2, 3
 CS_DIR_XLO_YLO, CS_DIR_XLO_YHI, CS_DIR_XHI_YLO, CS_DIR_XHI_YHI = 4, 5, 6, 7
-CS_HALO_RECORD_BYTES = 32
+CS_HALO_RECORD_BYTES = 40
 NO_SOURCE_SINK = 0xFFFFFFFF
 
 

@@ -207,10 +207,6 @@ uint32_t cs_register_no_local_plan(cs_engine* e) {
 }
 uint32_t cs_register_hlp(cs_engine* e, const cs_hlp_desc* d) {
   if (d->kind == CS_HLP_ROUTE) {
-    if (e->tile) {
-      e->error = "route planners are not available on a tile engine";
-      return UINT32_MAX;
-    }
     if (!d->route_plan || !(d->route_scale > 0.0) || !(d->route_arrive >= 0.0)) {
       e->error = "route planner: route_plan, route_scale > 0 and route_arrive >= 0 are required";
       return UINT32_MAX;
@@ -277,6 +273,21 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   s.waypoints.assign(d->waypoints_xy, d->waypoints_xy + 2 * d->n_waypoints);
   s.d.waypoints_xy = nullptr;
   uint32_t handle = (uint32_t)e->sinks.size();
+  if (e->tile && d->hlp < e->hlps.size() && e->hlps[d->hlp].kind == CS_HLP_ROUTE) {
+    // A tile cannot ask its host for a route in the middle of a step and stay in step with its
+    // neighbours: the route book is filled here, in sink order, the same on every tile (halo
+    // records carry route numbers).  Later legs start wherever an agent stands, so they cannot
+    // be planned ahead.
+    if (d->n_waypoints != 1) {
+      e->error = "route followers on a tile engine take source-sinks with one waypoint";
+      return UINT32_MAX;
+    }
+    s.spawn_route = e->route_lookup(d->hlp, d->source_x, d->source_y, s.waypoints[0], s.waypoints[1]);
+    if (!s.spawn_route) {
+      e->error = "route planner found no route for this source-sink (tile engines plan at registration)";
+      return UINT32_MAX;
+    }
+  }
   s.group = e->make_group(d->hlp, d->lp, d->agent_eyesight_range, (int32_t)handle);
   e->sinks.push_back(s);
   e->sinks_dirty = true;

@@ -134,7 +134,9 @@ class HighLevelPlanner:
 
     def _register(self, lib, engine):
         desc, keep = self._desc()
-        self._keepalive = keep
+        # one set of callback thunks per engine this planner is registered with (a tile mesh
+        # registers it with every tile); the engines hold the raw pointers
+        self._keepalive = getattr(self, "_keepalive", []) + list(keep)
         return lib.cs_register_hlp(engine, C.byref(desc))
 
 
@@ -380,6 +382,8 @@ class Simulation:
         desc.loop_forever = 1 if source_sink.loop_forever else 0
         desc.agent_eyesight_range = float(source_sink.agent_eyesight_range)
         handle = self._lib.cs_add_source_sink(self._engine, C.byref(desc))
+        if handle == 0xFFFFFFFF:
+            raise self._err()
         self._source_sinks[handle] = (source_sink, keep)
         return handle
 

@@ -128,9 +128,10 @@ def halo_capacity(layout, density_per_cell, halo_cells, slack=2.0):
 
 
 def _is_data_planner(source_sink):
-    """True when the sink's high-level planner runs on the device without host events."""
-    from .simulation import _DataPlan
-    return isinstance(source_sink.high_level_planner, _DataPlan)
+    """True when the sink's high-level planner runs on the device without host events.  A route
+    follower on a tile qualifies: its routes are planned when the sink is registered."""
+    from .simulation import RouteFollower, _DataPlan
+    return isinstance(source_sink.high_level_planner, (_DataPlan, RouteFollower))
 
 
 class _TileBase:

@@ -322,8 +322,71 @@ def test_full_size_crowd_invariants():
     assert moved.max() < 3 * 0.05 * 0.01
 
 
-def test_route_planners_are_refused_on_tile_engines():
-    from rmf_crowdsim_amd import CrowdSimError, RouteFollower
+def _route_scene(target, lp):
+    """Sixteen lanes whose walkers follow host-planned doglegs (RouteFollower) across the cuts."""
+    from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
+    from test_oracle_reference_kats import DoglegRoutes
+    routes = DoglegRoutes()
+    hlp = RouteFollower(routes, scale=4.0, arrive=0.1, speed=1.2)
+    for k in range(16):
+        y = 20.0 + 7.5 * k
+        left = k % 2 == 0
+        # ends 6 m higher / lower than it starts: lanes near the middle cross the other cut as well
+        src, dst = ((20.0, y), (120.0, y + 6.0)) if left else ((140.0, y), (40.0, y - 6.0))
+        target.add_source_sink(SourceSink(src, 1.0, SeededPoissonCrowd(1.5, 70 + k), hlp, lp, [dst], False, 2.0))
+    return routes
+
+
+@pytest.mark.parametrize("tiles,host_steps", [((2, 2), ()), ((3, 1), (300, 301, 650)), ((2, 2), range(1000))])
+def test_route_followers_across_tiles_match_single_engine(tiles, host_steps):
+    """CS_HLP_ROUTE on tiles: every tile plans the sinks' routes at registration (same route
+    numbers everywhere), the agent_cache entry of an agent (route, waypoint reached) travels in
+    its halo record, so a walker that changes tiles half-way along a dogleg carries on; spawns
+    through the device flags, through the host, or mixed."""
+    grid = dict(width=160.0, height=160.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1)
+    rs, rm = _route_scene(single, NoLocalPlan()), _route_scene(mesh, NoLocalPlan())
+    assert len(rm.calls) == 16 * len(mesh.engines) and len(rs.calls) == 0  # planned ahead on tiles only
+    for k in range(1000):
+        single.step(0.1, report=False)
+        mesh.step(0.1, report=k in host_steps)
+    a, b = single.read_agents(), mesh.read_agents()
+    owners = [len(e) for e in mesh.engines]
+    assert len(a) > 300 and a["id"].max() > 600 and sum(1 for n in owners if n > 0) >= 2
+    assert a.tobytes() == b.tobytes()
+    assert len(rs.calls) == 16 and len(rm.calls) == 16 * len(mesh.engines)
+
+
+def test_route_followers_with_zanlungo_across_tiles():
+    """The same lanes with the social force on: ghosts of route followers push owned ones."""
+    grid = dict(width=160.0, height=160.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 2), halo_cells=1)
+    lp = Zanlungo(0.05, 1.0, 0.0, 0.4, 2.0, 0.2)
+    _route_scene(single, lp), _route_scene(mesh, lp)
+    for k in range(80):  # (longer runs leave the reference model's finite range, DESIGN.md section 5)
+        single.step(0.1, report=False)
+        mesh.step(0.1, report=False)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 50 and np.isfinite(a["x"]).all() and a.tobytes() == b.tobytes()
+
+
+def test_route_planners_on_tiles_take_single_leg_sinks_only():
+    """Later legs start wherever the agent stands (rmf/mod.rs:217-236): they cannot be planned
+    ahead, and a tile cannot stop for its host in mid-step."""
+    from rmf_crowdsim_amd import CrowdSimError, MonotonicCrowd, RouteFollower, SourceSink
     mesh = LocalTileMesh(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)), (2, 1), halo_cells=1)
-    with pytest.raises(CrowdSimError, match="tile engine"):
-        mesh.add_agents(np.array([[5.0, 5.0]]), RouteFollower(lambda s, g: [s, g]), NoLocalPlan(), 2.0)
+    hlp = RouteFollower(lambda s, g: [s, g] if g[0] < 900.0 else None)
+    with pytest.raises(CrowdSimError, match="one waypoint"):
+        mesh.add_source_sink(SourceSink((5.0, 5.0), 1.0, MonotonicCrowd(1.0), hlp, NoLocalPlan(),
+                                        [(20.0, 5.0), (30.0, 5.0)], False, 2.0))
+    with pytest.raises(CrowdSimError, match="no route"):
+        mesh.add_source_sink(SourceSink((5.0, 5.0), 1.0, MonotonicCrowd(1.0), hlp, NoLocalPlan(),
+                                        [(950.0, 5.0)], False, 2.0))
+    # agents without a target stand still, as on a single engine (rmf/mod.rs:211-214)
+    mesh.add_agents(np.array([[5.0, 5.0], [30.0, 30.0]]), hlp, NoLocalPlan(), 2.0)
+    for _ in range(3):
+        mesh.step(0.1)
+    a = mesh.read_agents()
+    assert np.allclose(a["x"], [5.0, 30.0]) and np.allclose(a["y"], [5.0, 30.0])
