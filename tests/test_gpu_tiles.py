@@ -288,6 +288,65 @@ def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path):
     assert len(a) > 300 and a.tobytes() == both.tobytes()
 
 
+def _rank_nccl_single(port, out_path):
+    import os
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from rmf_crowdsim_amd.tiles import DistributedTiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        # stream order is all that separates pack -> P2P -> unpack in DistributedTiles.step: a
+        # buffer filled on the side stream, sent (to this rank itself) and read back on that
+        # stream, with no host synchronisation in between
+        side = torch.cuda.Stream()
+        ok = True
+        with torch.cuda.stream(side):
+            send = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+            recv = torch.zeros_like(send)
+            ops = [dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, recv, 0)]
+            for k in range(1, 6):
+                send.fill_(k)  # enqueued on `side`
+                for work in dist.batch_isend_irecv(ops):
+                    work.wait()
+                ok = ok and bool((recv == k).all().item())
+        grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+        tiles = DistributedTiles(LocationHash2D(**grid), (1, 1), halo_cells=1, device=0)
+        _sink_scene(tiles)
+        for k in range(400):
+            tiles.step(0.05, report=(k in (150, 151)))  # flags all-reduced on the device, twice via the host
+        with open(out_path, "wb") as f:
+            pickle.dump((ok, tiles.read_agents()), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_tiles_on_the_rccl_backend_single_rank(tmp_path):
+    """The test box has one GPU, so the RCCL transport can only run with one rank: this covers
+    the backend's calls as DistributedTiles makes them (process group bound to the device,
+    all-reduce of the spawn flags as a device tensor on the engine's stream, batched
+    isend/irecv ordered by that stream alone).  Neighbour traffic is covered by the gloo ranks."""
+    import pickle
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "nccl.pkl")
+    p = ctx.Process(target=_rank_nccl_single, args=(29727, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ok, mine = pickle.load(open(out, "rb"))
+    assert ok
+    single = Simulation(LocationHash2D(60.0, 60.0, 2.0, (0.0, 0.0)))
+    _sink_scene(single)
+    for _ in range(400):
+        single.step(0.05, report=False)
+    a = single.read_agents()
+    assert len(a) > 300 and a.tobytes() == mine.tobytes()
+
+
 def test_full_size_crowd_invariants():
     """BASELINE.json configs[1] at its full size (1M agents, 2.5 agents/m^2, eyesight 2 m, cell
     2 m), through properties that need no oracle run: the LDS-tiled and the gather kernel give
