@@ -192,7 +192,7 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
     cs_device_cfg cfg{};
     cfg.device_ordinal = device;
     engine_ = cs_create(&g, &cfg);
-    if (!engine_) throw std::runtime_error("cs_create failed: no HIP device (the engine has no CPU path)");
+    if (!engine_) throw std::runtime_error(std::string("cs_create failed: ") + cs_last_error(nullptr));
   }
   ~Simulation() { cs_destroy(engine_); }
   Simulation(const Simulation&) = delete;

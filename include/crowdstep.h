@@ -201,6 +201,8 @@ uint32_t cs_abi_version(void);
 /* Simulation::new(LocationHash2D::new(..))   lib.rs:103, location_hash_2d.rs:33 */
 cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg);
 void cs_destroy(cs_engine*);
+/* The message of the last Err of this engine; with a null engine, why the calling thread's
+ * last cs_create returned null (no device, grid beyond 32-bit cell indices, allocation). */
 const char* cs_last_error(const cs_engine*);
 /* "hip:<gcnArchName>" for the product, "oracle:f64" for the test oracle */
 const char* cs_backend_name(const cs_engine*);

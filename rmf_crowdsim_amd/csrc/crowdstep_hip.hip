@@ -75,32 +75,35 @@ void cs_destroy(cs_engine* e) {
   delete e;
 }
 
+// why the last cs_create of this thread returned null (cs_last_error(nullptr))
+static thread_local std::string g_create_error;
+static cs_engine* create_failed(cs_engine* e, const std::string& why) {
+  g_create_error = why;
+  fprintf(stderr, "crowdstep: %s\n", why.c_str());
+  if (e) cs_destroy(e);
+  return nullptr;
+}
+
 // Simulation::new(LocationHash2D::new(..)), lib.rs:103 + location_hash_2d.rs:33-51
 cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
-  if (!grid) return nullptr;
+  if (!grid) return create_failed(nullptr, "null grid description");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    fprintf(stderr, "crowdstep: no HIP device visible; the engine has no CPU fallback\n");
-    return nullptr;
-  }
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return create_failed(nullptr, "no HIP device visible; the engine has no CPU fallback");
   cs_engine* e = new cs_engine();
   e->grid = *grid;
   e->device = cfg ? cfg->device_ordinal : 0;
   e->flags = cfg ? cfg->flags : 0;
-  if (e->device < 0 || e->device >= ndev || hipSetDevice(e->device) != hipSuccess) {
-    delete e;
-    return nullptr;
-  }
+  if (e->device < 0 || e->device >= ndev || hipSetDevice(e->device) != hipSuccess)
+    return create_failed(e, "no HIP device with ordinal " + std::to_string(e->device));
   // (width / cell) as usize is the row stride, used on BOTH axes, and the number of x rows
   // that fit is len / stride = (height / cell) as usize (location_hash_2d.rs:36-37,59)
   e->gnx = sat_usize(grid->width / grid->cell_size);
   e->gny = sat_usize(grid->height / grid->cell_size);
   unsigned __int128 gnc = (unsigned __int128)e->gnx * e->gny;
-  if (gnc >= 0x7FFFFFFFull || e->gnx >= 0x7FFFFFFFull) {
-    fprintf(stderr, "crowdstep: grid too large for 32-bit cell indices\n");
-    delete e;
-    return nullptr;
-  }
+  if (gnc >= 0x7FFFFFFFull || e->gnx >= 0x7FFFFFFFull)
+    return create_failed(e, "grid too large for 32-bit cell indices (" + std::to_string(e->gnx) + " x " +
+                                std::to_string(e->gny) + " cells)");
   e->nx = e->gnx;
   e->ny = e->gny;
   std::memset(&e->gdev, 0, sizeof e->gdev);
@@ -108,11 +111,8 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (cfg && (cfg->tile_cx1 | cfg->tile_cy1)) {
     const uint32_t H = cfg->halo_cells;
     if (cfg->tile_cx0 >= cfg->tile_cx1 || cfg->tile_cy0 >= cfg->tile_cy1 || cfg->tile_cx1 > e->gny ||
-        cfg->tile_cy1 > e->gnx || H == 0) {
-      fprintf(stderr, "crowdstep: bad tile rectangle / halo_cells\n");
-      delete e;
-      return nullptr;
-    }
+        cfg->tile_cy1 > e->gnx || H == 0)
+      return create_failed(e, "bad tile rectangle / halo_cells");
     e->tile = true;
     e->halo_cells = H;
     const uint32_t lx0 = cfg->tile_cx0 > H ? cfg->tile_cx0 - H : 0;
@@ -145,10 +145,8 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (cfg && cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
-      delete e;
-      return nullptr;
-    }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+      return create_failed(e, "hipStreamCreate failed");
     e->own_stream = true;
   }
   hipDeviceProp_t prop;
@@ -181,14 +179,12 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   }
   if (!ok || e->upload_sinks() != 0 ||
       e->reserve(cfg && cfg->capacity_hint ? cfg->capacity_hint : 1024) != 0) {
-    fprintf(stderr, "crowdstep: device allocation failed: %s\n", e->error.c_str());
-    cs_destroy(e);
-    return nullptr;
+    return create_failed(e, "device allocation failed: " + e->error);
   }
   return e;
 }
 
-const char* cs_last_error(const cs_engine* e) { return e ? e->error.c_str() : "null engine"; }
+const char* cs_last_error(const cs_engine* e) { return e ? e->error.c_str() : g_create_error.c_str(); }
 const char* cs_backend_name(const cs_engine* e) { return e ? e->backend.c_str() : ""; }
 
 uint32_t cs_register_zanlungo(cs_engine* e, const cs_zanlungo_params* p) {

@@ -295,7 +295,7 @@ class Simulation:
         self.spatial_index = spatial_index
         self._engine = self._lib.cs_create(C.byref(grid), C.byref(cfg))
         if not self._engine:
-            raise CrowdSimError("cs_create failed (no usable HIP device?)")
+            raise CrowdSimError("cs_create failed: " + self._lib.cs_last_error(None).decode())
         self._lib.cs_event_recording(self._engine, 0)  # no listeners yet (lib.rs:88)
         self._planner_handles = {}
         self._planners_alive = []

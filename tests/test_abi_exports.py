@@ -40,5 +40,5 @@ def test_no_cpu_fallback_without_a_device():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     from rmf_crowdsim_amd import CrowdSimError, LocationHash2D, Simulation
-    with pytest.raises(CrowdSimError):
+    with pytest.raises(CrowdSimError, match="no HIP device visible; the engine has no CPU fallback"):
         Simulation(LocationHash2D(10.0, 10.0, 1.0, (0.0, 0.0)))

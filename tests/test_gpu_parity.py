@@ -933,3 +933,13 @@ def test_bands_wider_than_the_builders_lds_prefix():
     assert len(outs[0]) == len(pts) and outs[0].tobytes() == outs[1].tobytes()
     speed = np.hypot(outs[0]["vx"], outs[0]["vy"])
     assert (np.abs(speed - np.hypot(0.0005, 0.001)) > 1e-9).mean() > 0.5  # forces act
+
+
+def test_create_failures_say_why():
+    """cs_create returns null; cs_last_error(NULL) carries the reason (the reference would try to
+    allocate (w / cell) * (h / cell) Vecs, location_hash_2d.rs:38-41)."""
+    from rmf_crowdsim_amd import CrowdSimError
+    with pytest.raises(CrowdSimError, match="grid too large for 32-bit cell indices"):
+        Simulation(LocationHash2D(1.0e6, 1.0e6, 1.0, (0.0, 0.0)))
+    with pytest.raises(CrowdSimError, match="no HIP device with ordinal 99"):
+        Simulation(LocationHash2D(10.0, 10.0, 1.0, (0.0, 0.0)), device=99)
