@@ -81,6 +81,7 @@ static cs_engine* create_failed(cs_engine* e, const std::string& why) {
   g_create_error = why;
   fprintf(stderr, "crowdstep: %s\n", why.c_str());
   if (e) cs_destroy(e);
+  (void)hipGetLastError();  // the failure is reported here: leave no stale error for the caller's next HIP call
   return nullptr;
 }
 
@@ -94,8 +95,11 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   e->grid = *grid;
   e->device = cfg ? cfg->device_ordinal : 0;
   e->flags = cfg ? cfg->flags : 0;
-  if (e->device < 0 || e->device >= ndev || hipSetDevice(e->device) != hipSuccess)
-    return create_failed(e, "no HIP device with ordinal " + std::to_string(e->device));
+  if (e->device < 0 || e->device >= ndev || hipSetDevice(e->device) != hipSuccess) {
+    const int ordinal = e->device;
+    delete e;  // nothing allocated yet (and cs_destroy would select the device again)
+    return create_failed(nullptr, "no HIP device with ordinal " + std::to_string(ordinal));
+  }
   // (width / cell) as usize is the row stride, used on BOTH axes, and the number of x rows
   // that fit is len / stride = (height / cell) as usize (location_hash_2d.rs:36-37,59)
   e->gnx = sat_usize(grid->width / grid->cell_size);
