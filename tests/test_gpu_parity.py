@@ -307,6 +307,27 @@ def test_tiled_and_gather_kernels_agree_bitwise(rows, monkeypatch):
     assert outs[0].tobytes() == outs[1].tobytes()
 
 
+@pytest.mark.parametrize("stage_cap", ["40", "200"])
+def test_band_windows_stay_within_the_launch_when_the_staging_bound_cuts_them(stage_cap, monkeypatch):
+    """The step kernel's launch is sized for windows that fill a workgroup (2 * agents / 256 + one
+    per band).  Windows cut short by the staging bound can be far more numerous; the builder then
+    hands the rest of a band to its last window, which the kernel walks in chunks (through its
+    gather path where the tile does not fit the LDS).  CS_TILE_STAGE_CAP makes the builder believe
+    in a tiny staging area: every window is cut (at 40: to one column), nobody may be lost."""
+    outs = []
+    for flags, cap in ((1, None), (2, None), (2, stage_cap)):
+        if cap is None:
+            monkeypatch.delenv("CS_TILE_STAGE_CAP", raising=False)
+        else:
+            monkeypatch.setenv("CS_TILE_STAGE_CAP", cap)
+        s, _ = _crowd(Simulation, 30000, 1.0, 2.0, scenes.WALK_SPEED, flags=flags)
+        for _ in range(3):
+            s.step(1e-4, report=False)
+        outs.append(s.read_agents())
+    assert len(outs[2]) == 30000 and len(np.unique(outs[2]["id"])) == 30000
+    assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
+
+
 @pytest.mark.parametrize("crowd", ["random", "hotspots"])
 def test_tiled_and_gather_kernels_agree_bitwise_when_lists_overflow(crowd, monkeypatch):
     """Crowds whose neighbour counts scatter: some lanes hold more neighbours than the LDS list
