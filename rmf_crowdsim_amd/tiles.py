@@ -200,6 +200,20 @@ class LocalTileMesh(_TileBase):
         for sim in self.engines:
             sim.add_event_listener(listener)
 
+    def remove_source_sink(self, handle):
+        for sim in self.engines:  # same handles everywhere: every tile registered every sink
+            sim.remove_source_sink(handle)
+
+    def remove_agents(self, agent):
+        """lib.rs:176-192.  Between steps every agent is held by exactly one tile (its owner)."""
+        from .simulation import CrowdSimError
+        for sim in self.engines:
+            if sim._lib.cs_remove_agent(sim._engine, int(agent)) == 0:
+                sim._agents_cache = None
+                sim._dispatch_events()
+                return
+        raise CrowdSimError("unknown agent id")
+
     def _exchange(self, axis):
         for sim in self.engines:
             sim.halo_pack(axis)
@@ -369,6 +383,23 @@ class DistributedTiles(_TileBase):
         self._n_sinks = getattr(self, "_n_sinks", 0) + 1
         self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
         return self.sim.add_source_sink(source_sink)
+
+    def remove_source_sink(self, handle):
+        self.sim.remove_source_sink(handle)
+
+    def remove_agents(self, agent):
+        """lib.rs:176-192 on every rank (collective): the owner removes, the others learn of it."""
+        from .simulation import CrowdSimError
+        found = self.sim._lib.cs_remove_agent(self.sim._engine, int(agent)) == 0
+        if found:
+            self.sim._agents_cache = None
+            self.sim._dispatch_events()
+        flag = self.torch.tensor([1 if found else 0], dtype=self.torch.int32)
+        if self.dist.get_backend() == "nccl":
+            flag = flag.to(self.stream.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if int(flag.item()) == 0:
+            raise CrowdSimError("unknown agent id")
 
     def step(self, dur, report=False):
         with self.torch.cuda.stream(self.stream):

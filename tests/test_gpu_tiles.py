@@ -381,6 +381,36 @@ def test_full_size_crowd_invariants():
     assert moved.max() < 3 * 0.05 * 0.01
 
 
+def test_removals_on_a_tile_mesh_match_the_single_engine():
+    """remove_agents / remove_source_sink through the mesh (lib.rs:164-192): the tile that holds
+    the agent removes it; an id nobody holds is an Err."""
+    from rmf_crowdsim_amd import CrowdSimError
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 2), halo_cells=1)
+    for t in (single, mesh):
+        _sink_scene(t)
+    for k in range(300):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    alive = single.read_agents()["id"]
+    victims = [int(alive[0]), int(alive[len(alive) // 2]), int(alive[-1])]
+    for t in (single, mesh):
+        for v in victims:
+            t.remove_agents(v)
+        t.remove_source_sink(3)
+    with pytest.raises(CrowdSimError, match="unknown agent id"):
+        mesh.remove_agents(victims[0])
+    with pytest.raises(CrowdSimError, match="unknown agent id"):
+        mesh.remove_agents(10 ** 9)
+    for k in range(300):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and not set(victims) & set(a["id"].tolist())
+    assert a.tobytes() == b.tobytes()
+
+
 def _route_scene(target, lp):
     """Sixteen lanes whose walkers follow host-planned doglegs (RouteFollower) across the cuts."""
     from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
