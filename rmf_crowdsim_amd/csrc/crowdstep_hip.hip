@@ -162,7 +162,18 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
     (void)hipGetLastError();  // (wide cells: a large staged tile)
+  {  // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB
+    hipFuncAttributes fa;
+    size_t st = 0;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled<true>)) == hipSuccess)
+      st = std::max(st, (size_t)fa.sharedSizeBytes);
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled<false>)) == hipSuccess)
+      st = std::max(st, (size_t)fa.sharedSizeBytes);
+    (void)hipGetLastError();
+    if (st) e->tile_static_lds = (uint32_t)st;
+  }
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_MIN_ROWS")) e->tile_min_rows = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_SPILL_ROWS")) e->tile_spill_rows = atoi(v);
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
