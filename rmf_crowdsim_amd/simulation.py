@@ -428,7 +428,10 @@ class Simulation:
 
     # -- observation --
     def read_agents(self):
-        """Structured array (id, x, y, vx, vy, next_waypoint, eyesight_range), ascending id."""
+        """Structured array (id, x, y, vx, vy, next_waypoint, eyesight_range), ascending id.
+        Steps taken without a report return before the device has finished: an Err of such a
+        step ("Index out of bounds") is raised here, by the first call that waits for it."""
+        self.synchronize()
         n = self._lib.cs_agent_count(self._engine)
         buf = (_abi.AgentView * max(n, 1))()
         got = self._lib.cs_read_agents(self._engine, buf, n)

@@ -964,3 +964,25 @@ def test_create_failures_say_why():
         Simulation(LocationHash2D(1.0e6, 1.0e6, 1.0, (0.0, 0.0)))
     with pytest.raises(CrowdSimError, match="no HIP device with ordinal 99"):
         Simulation(LocationHash2D(10.0, 10.0, 1.0, (0.0, 0.0)), device=99)
+
+
+def test_an_unreported_step_that_fails_is_reported_by_the_next_readback():
+    """step(report=False) returns before the device has finished.  A crowd that walks off the
+    grid in such a step ("Index out of bounds", location_hash_2d.rs:61-63) must not just shrink:
+    the first call that waits for the device raises, as the reference's step would have."""
+    from rmf_crowdsim_amd import CrowdSimError
+    pts = np.array([(x + 0.5, y + 0.5) for x in range(30, 40) for y in range(10, 30)], dtype=np.float64)
+    for hurry in (False, True):
+        sim = Simulation(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)))
+        sim.add_agents(pts, StubHighLevelPlan((4.0, 0.0)), NoLocalPlan(), 2.0)  # 0.4 m per step towards x = 40
+        if hurry:
+            with pytest.raises(CrowdSimError, match="Index out of bounds"):
+                for _ in range(60):
+                    sim.step(0.1, report=True)
+        else:
+            for _ in range(60):
+                sim.step(0.1, report=False)
+            with pytest.raises(CrowdSimError, match="Index out of bounds"):
+                sim.read_agents()
+            with pytest.raises(CrowdSimError, match="Index out of bounds"):
+                sim.step(0.1)  # the engine stays failed

@@ -411,6 +411,76 @@ def test_removals_on_a_tile_mesh_match_the_single_engine():
     assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_meshes_match_the_single_engine(seed):
+    """Random grids, cell sizes, eyesight ranges (halo up to 7 cells), mesh shapes, exchange
+    schedules, walking speeds and planners: same bits as one engine, and the same failures (the
+    reference model leaves its finite range at walking speed, DESIGN.md section 5: then both
+    sides must report "Index out of bounds", give or take the steps in flight).  One allowed
+    difference: a tile's grid edges are strict, the single engine clamps agents that walk below
+    the grid like the reference does."""
+    import math
+    from rmf_crowdsim_amd import CrowdSimError
+    from rmf_crowdsim_amd.simulation import IdParityHighLevelPlan
+    from test_gpu_parity import _fuzz_case
+    rng = np.random.default_rng(5000 + seed)
+    grid, pts, eyesight, speed, spacing = _fuzz_case(3000 + seed)
+    cell = grid["cell_size"]
+    halo = max(1, math.ceil(eyesight / cell - 1e-6))
+    nx, ny = int(grid["width"] / cell), int(grid["height"] / cell)
+    tiles = [(2, 2), (3, 1), (1, 3), (2, 3), (4, 2)][int(rng.integers(0, 5))]
+    if min(ny // tiles[0], nx // tiles[1]) < 2 * halo + 1:
+        tiles = (2, 1)
+    if ny // tiles[0] < 2 * halo + 1:
+        pytest.skip("grid too small for two tiles with this halo")
+    R = min(0.2, 0.45 * spacing)
+    lp = Zanlungo(1.0, 1.0, 0.0, 2.0 * R, 2.0, R) if rng.random() < 0.7 else NoLocalPlan()
+    walk = float(rng.choice([0.01, 0.3, 1.3]))
+    phases = int(rng.choice([1, 2]))
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, phases=phases)
+    n = len(pts)
+    for t in (single, mesh):
+        t.add_agents(pts[: n // 2], StubHighLevelPlan((walk * 0.6, walk)), lp, eyesight)
+        t.add_agents(pts[n // 2:], IdParityHighLevelPlan((-walk, walk * 0.3)), lp, eyesight * 0.8)
+
+    def status(t):
+        try:
+            for e in (t.engines if isinstance(t, LocalTileMesh) else [t]):
+                e.synchronize()
+            return None
+        except CrowdSimError as e:
+            return str(e)
+
+    def advance(t, steps):
+        for _ in range(steps):
+            try:
+                t.step(0.05, report=False)
+            except CrowdSimError as e:
+                return str(e)
+        return status(t)
+
+    steps = 40 if isinstance(lp, NoLocalPlan) else (3 if walk > 0.1 else 20)
+    es = em = None
+    for _ in range(steps):
+        es, em = es or advance(single, 1), em or advance(mesh, 1)
+        if es or em:
+            break
+    if (es is None) != (em is None):  # the failing step may differ by the steps in flight
+        if es is None:
+            es = advance(single, 8)
+        else:
+            em = advance(mesh, 8)
+    if es is None and em is not None:
+        single.step(0.05)
+        assert single.last_report["n_clamped"] > 0, f"mesh: {em}, single engine healthy"
+        return
+    assert (es is None) == (em is None), f"single: {es}, mesh: {em}"
+    if es is None:
+        a, b = single.read_agents(), mesh.read_agents()
+        assert len(a) == len(b) == n and a.tobytes() == b.tobytes()
+
+
 def _route_scene(target, lp):
     """Sixteen lanes whose walkers follow host-planned doglegs (RouteFollower) across the cuts."""
     from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
