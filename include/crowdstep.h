@@ -229,9 +229,12 @@ void cs_remove_source_sink(cs_engine*, uint32_t handle);
 /* ---- the hot path ------------------------------------------------------ */
 /* Simulation::step(dur), dt_seconds = dur.as_secs_f64()          lib.rs:195-383
  * report may be NULL (then the call does not wait for the device unless
- * source-sinks or callback planners need the host). */
+ * source-sinks or callback planners need the host).  The Err of a step that was not
+ * waited for ("Index out of bounds") is returned by the next call that does wait:
+ * cs_synchronize, a cs_step with a report (or one that needs the host), and it makes
+ * cs_read_agents return 0 once (cs_last_error says why); later steps are refused. */
 int cs_step(cs_engine*, double dt_seconds, cs_step_report* report);
-/* Wait until every queued step has finished on the device. */
+/* Wait until every queued step has finished on the device; 0, or the Err of one of them. */
 int cs_synchronize(cs_engine*);
 
 /* ---- observation ------------------------------------------------------- */
