@@ -481,6 +481,69 @@ def test_random_meshes_match_the_single_engine(seed):
         assert len(a) == len(b) == n and a.tobytes() == b.tobytes()
 
 
+def _random_sink_scene(t, rng_seed):
+    from rmf_crowdsim_amd import MonotonicCrowd, SeededPoissonCrowd, SourceSink
+    rng = np.random.default_rng(rng_seed)
+    n_sinks = int(rng.integers(2, 12))
+    lp = NoLocalPlan() if rng.random() < 0.6 else Zanlungo(0.02, 1.0, 0.0, 0.4, 2.0, 0.2)
+    for k in range(n_sinks):
+        src = rng.uniform(10.0, 70.0, size=2)
+        wps = [tuple(rng.uniform(8.0, 72.0, size=2)) for _ in range(int(rng.integers(1, 4)))]
+        d = np.array(wps[0]) - src  # roughly towards the first waypoint, so that some arrive
+        v = d / max(np.linalg.norm(d), 1e-9) * float(rng.uniform(0.5, 1.5))
+        gen = (MonotonicCrowd(float(rng.uniform(0.5, 12.0))) if rng.random() < 0.5
+               else SeededPoissonCrowd(float(rng.uniform(0.5, 6.0)), int(rng.integers(1, 1 << 30))))
+        t.add_source_sink(SourceSink(tuple(src), float(rng.uniform(0.4, 2.0)), gen, StubHighLevelPlan(tuple(v)), lp,
+                                     wps, bool(rng.random() < 0.3), float(rng.uniform(1.0, 3.0))))
+    return isinstance(lp, NoLocalPlan)
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_source_sinks_engine_oracle_and_mesh_agree(seed):
+    """Random source-sinks (positions, rates, generators, one to three waypoints, looping or not,
+    sink radii, eyesight) on one engine, on the f64 oracle and on a mesh (2 x 2, 3 x 1, 1 x 2:
+    a tile with more rows than columns once hid sources from the occupancy test): the same
+    spawns, arrivals and removals every step, the same events, the same bits on the mesh."""
+    import math
+    from rmf_crowdsim_amd import CrowdSimError
+    from oracle_sim import OracleSimulation
+    from test_gpu_parity import max_rel_err
+    from test_oracle_reference_kats import MockEventListener
+    grid = dict(width=80.0, height=80.0, cell_size=float([1.0, 2.0, 2.5][seed % 3]), offset=(0.0, 0.0))
+    sims = [Simulation(LocationHash2D(**grid)), OracleSimulation(LocationHash2D(**grid)),
+            LocalTileMesh(LocationHash2D(**grid), [(2, 2), (3, 1), (1, 2)][seed % 3],
+                          halo_cells=math.ceil(3.0 / grid["cell_size"]))]
+    listeners = []
+    for t in sims:
+        plain = _random_sink_scene(t, 900 + seed)
+        listeners.append(MockEventListener())
+        t.add_event_listener(listeners[-1])
+    traces, failed = [[], [], []], [None, None, None]
+    for k in range(200 if plain else 60):
+        for i, t in enumerate(sims):
+            try:
+                t.step(0.1)
+            except CrowdSimError as e:
+                failed[i] = (k, str(e))
+                continue
+            reports = [e.last_report for e in t.engines] if i == 2 else [t.last_report]
+            traces[i].append((len(t),) + tuple(sum(r[key] for r in reports)
+                                               for key in ("n_spawned", "n_destroyed", "n_waypoint_hits")))
+        if any(failed):
+            break
+    assert failed[0] == failed[1] and (failed[2] is None) == (failed[0] is None), failed
+    if failed[0]:
+        return  # the model left its finite range on all three (DESIGN.md section 5)
+    assert traces[0] == traces[1] == traces[2]
+    assert listeners[0].added == listeners[1].added and listeners[0].removed == listeners[1].removed
+    assert sorted(listeners[0].added) == sorted(listeners[2].added)
+    assert sorted(listeners[0].removed) == sorted(listeners[2].removed)
+    a, b, c = sims[0].read_agents(), sims[1].read_agents(), sims[2].read_agents()
+    assert a.tobytes() == c.tobytes() and (a["next_waypoint"] == b["next_waypoint"]).all()
+    ok = np.isfinite(b["x"])
+    assert len(a) == 0 or max_rel_err(a[ok], b[ok], 80.0) <= 1e-4
+
+
 def _route_scene(target, lp):
     """Sixteen lanes whose walkers follow host-planned doglegs (RouteFollower) across the cuts."""
     from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
