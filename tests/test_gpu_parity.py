@@ -986,3 +986,72 @@ def test_an_unreported_step_that_fails_is_reported_by_the_next_readback():
                 sim.read_agents()
             with pytest.raises(CrowdSimError, match="Index out of bounds"):
                 sim.step(0.1)  # the engine stays failed
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_removals_and_queries_between_steps_match_the_oracle(seed):
+    """Random source-sink scenes with kinematic walkers (NoLocalPlan), and between the steps, at
+    random: remove_agents (again: must be an Err), remove_source_sink, radius queries and k-NN
+    anywhere (also outside the grid).  A query re-sorts the state into the other buffer; slots
+    there beyond the live records once kept an older step's records, and a removal followed by a
+    query brought one of them back to life as a duplicate."""
+    import math
+    import test_gpu_tiles
+    from rmf_crowdsim_amd import CrowdSimError
+    from test_oracle_reference_kats import MockEventListener
+    rng = np.random.default_rng(7000 + seed)
+    cell = float(rng.choice([1.0, 2.0, 2.5, 4.0]))
+    off = (float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)))
+    grid = dict(width=80.0, height=80.0, cell_size=cell, offset=off)
+    sims = [Simulation(LocationHash2D(**grid)), OracleSimulation(LocationHash2D(**grid))]
+    extra = rng.uniform(12.0, 68.0, size=(int(rng.integers(0, 300)), 2)) + np.array(off)
+    vel = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))
+    listeners = []
+    saved, test_gpu_tiles.Zanlungo = test_gpu_tiles.Zanlungo, (lambda *a: NoLocalPlan())
+    try:
+        for t in sims:
+            test_gpu_tiles._random_sink_scene(t, 1900 + seed)
+    finally:
+        test_gpu_tiles.Zanlungo = saved
+    for t in sims:
+        if len(extra):
+            t.add_agents(extra, StubHighLevelPlan(vel), NoLocalPlan(), 2.0)
+        listeners.append(MockEventListener())
+        t.add_event_listener(listeners[-1])
+    for k in range(120):
+        for t in sims:
+            t.step(0.1)
+        assert len(sims[0]) == len(sims[1])
+        a = sims[0].read_agents()
+        if len(a) and rng.random() < 0.3:
+            victim = int(a["id"][int(rng.integers(0, len(a)))])
+            for t in sims:
+                t.remove_agents(victim)
+                with pytest.raises(CrowdSimError):
+                    t.remove_agents(victim)
+        if rng.random() < 0.03:
+            handle = int(rng.integers(0, 12))
+            for t in sims:
+                t.remove_source_sink(handle)
+        if rng.random() < 0.5:
+            q, r = rng.uniform(-10.0, 90.0, size=2) + np.array(off), float(rng.choice([0.3, 1.0, 2.5, 7.0, 30.0]))
+            ra, rb = sims[0].get_neighbours_in_radius(r, q), sims[1].get_neighbours_in_radius(r, q)
+            if ra != rb:  # only an agent on the rim (f32 / f64) may differ
+                b = sims[1].read_agents()
+                pos = {int(i): (x, y) for i, x, y in zip(b["id"], b["x"], b["y"])}
+                diff = set(ra) ^ set(rb)
+                assert all(abs(math.hypot(pos[i][0] - q[0], pos[i][1] - q[1]) - r) < 1e-4 * max(r, 1.0) for i in diff)
+                assert [i for i in ra if i not in diff] == [i for i in rb if i not in diff]
+        if len(a) and rng.random() < 0.4:
+            q, kk = rng.uniform(-10.0, 90.0, size=2) + np.array(off), int(rng.choice([1, 3, 10, 50, 1000]))
+            got = sims[0].get_nearest_neighbours(kk, q)
+            now = sims[0].read_agents()
+            d = np.hypot(now["x"] - q[0], now["y"] - q[1])
+            order = np.argsort(d, kind="stable")[:kk]
+            if got != [int(i) for i in now["id"][order]]:  # near-ties may swap
+                assert len(got) == len(order)
+                assert np.allclose(sorted(d[np.isin(now["id"], got)]), sorted(d[order]), rtol=1e-5, atol=1e-5)
+    assert listeners[0].added == listeners[1].added and listeners[0].removed == listeners[1].removed
+    a, b = sims[0].read_agents(), sims[1].read_agents()
+    assert (a["id"] == b["id"]).all() and (a["next_waypoint"] == b["next_waypoint"]).all()
+    assert len(a) == 0 or max_rel_err(a, b, 80.0) <= 1e-4
