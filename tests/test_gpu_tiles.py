@@ -594,6 +594,64 @@ def test_route_followers_with_zanlungo_across_tiles():
     assert len(a) > 50 and np.isfinite(a["x"]).all() and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_route_followers_engine_oracle_and_mesh_agree(seed):
+    """Random source-sinks whose walkers follow host-planned doglegs (CS_HLP_ROUTE): one or two
+    planners with random hash scales, arrival radii and speeds, refused goals, one to three
+    waypoints (the later legs are planned from wherever the walker stands), looping or not,
+    steps with and without a report mixed.  Engine and oracle: the same events, waypoint states,
+    planner calls and positions; even seeds (single-leg sinks) also on a mesh: the same bits."""
+    import math
+    from rmf_crowdsim_amd import MonotonicCrowd, RouteFollower, SeededPoissonCrowd, SourceSink
+    from oracle_sim import OracleSimulation
+    from test_oracle_reference_kats import DoglegRoutes, MockEventListener
+
+    def scene(t, single_leg):
+        rng = np.random.default_rng(2900 + seed)
+        routes = DoglegRoutes()
+        hlps = [RouteFollower(routes, scale=float(rng.choice([0.5, 1.0, 4.0])), arrive=float(rng.choice([0.05, 0.1, 0.3])),
+                              speed=float(rng.uniform(0.6, 1.5))) for _ in range(int(rng.integers(1, 3)))]
+        for _ in range(int(rng.integers(2, 10))):
+            src = rng.uniform(10.0, 70.0, size=2)
+            wps = [tuple(rng.uniform(8.0, 72.0, size=2)) for _ in range(1 if single_leg else int(rng.integers(1, 4)))]
+            if rng.random() < 0.1 and not single_leg:
+                wps[0] = (950.0, float(wps[0][1]))  # a goal the planner refuses: the walker stays
+            gen = (MonotonicCrowd(float(rng.uniform(0.5, 8.0))) if rng.random() < 0.5
+                   else SeededPoissonCrowd(float(rng.uniform(0.5, 4.0)), int(rng.integers(1, 1 << 30))))
+            t.add_source_sink(SourceSink(tuple(src), float(rng.uniform(0.4, 2.0)), gen,
+                                         hlps[int(rng.integers(0, len(hlps)))], NoLocalPlan(), wps,
+                                         bool(rng.random() < 0.3) and not single_leg, float(rng.uniform(1.0, 3.0))))
+        return routes
+
+    single_leg = seed % 2 == 0
+    cell = float([1.0, 2.0, 2.5][seed % 3])
+    grid = dict(width=80.0, height=80.0, cell_size=cell, offset=(0.0, 0.0))
+    sims = [Simulation(LocationHash2D(**grid)), OracleSimulation(LocationHash2D(**grid))]
+    if single_leg:
+        sims.append(LocalTileMesh(LocationHash2D(**grid), [(2, 2), (3, 1), (1, 2), (2, 3)][seed % 4],
+                                  halo_cells=math.ceil(3.0 / cell)))
+    listeners, planners = [], []
+    for t in sims:
+        planners.append(scene(t, single_leg))
+        listeners.append(MockEventListener())
+        t.add_event_listener(listeners[-1])
+    for k in range(250):
+        for i, t in enumerate(sims):
+            t.step(0.1, report=(k % 7 != 3) or i == 1)
+    a, b = sims[0].read_agents(), sims[1].read_agents()
+    assert listeners[0].added == listeners[1].added and listeners[0].removed == listeners[1].removed
+    assert (a["id"] == b["id"]).all() and (a["next_waypoint"] == b["next_waypoint"]).all()
+    assert len(a) == 0 or float(np.hypot(a["x"] - b["x"], a["y"] - b["y"]).max()) <= 1e-4 * 80.0
+    # the same cache misses in the same order (start points: f32 cell offsets against f64)
+    assert len(planners[0].calls) == len(planners[1].calls)
+    assert not planners[0].calls or np.allclose(np.array(planners[0].calls, dtype=float),
+                                                np.array(planners[1].calls, dtype=float), rtol=0, atol=1e-3)
+    if single_leg:
+        assert a.tobytes() == sims[2].read_agents().tobytes()
+        assert sorted(listeners[0].added) == sorted(listeners[2].added)
+        assert sorted(listeners[0].removed) == sorted(listeners[2].removed)
+
+
 def test_route_planners_on_tiles_take_single_leg_sinks_only():
     """Later legs start wherever the agent stands (rmf/mod.rs:217-236): they cannot be planned
     ahead, and a tile cannot stop for its host in mid-step."""
