@@ -241,7 +241,29 @@ def test_host_queries_between_halo_exchange_and_step_are_harmless():
     assert len(b) == n and a.tobytes() == b.tobytes()
 
 
-def _rank_sinks(rank, world, port, out_path):
+def _two_rank_scene(kind, target):
+    """sinks: constant-velocity lanes; routes: the dogleg route followers; random: a random
+    source-sink scene with kinematic walkers; `target` is an engine, a mesh or a rank's tile."""
+    if kind == "sinks":
+        _sink_scene(target)
+        return dict(width=60.0, height=60.0), 0.05
+    if kind == "routes":
+        _route_scene(target, NoLocalPlan())
+        return dict(width=160.0, height=160.0), 0.1
+    import sys
+    saved, mod = Zanlungo, sys.modules[__name__]
+    mod.Zanlungo = lambda *a: NoLocalPlan()
+    try:
+        _random_sink_scene(target, 977)
+    finally:
+        mod.Zanlungo = saved
+    return dict(width=80.0, height=80.0), 0.1
+
+
+_TWO_RANK_GRID = {"sinks": (60.0, 0.05), "routes": (160.0, 0.1), "random": (80.0, 0.1)}
+
+
+def _rank_sinks(rank, world, port, out_path, kind, layout):
     import os
     import pickle
     import torch.distributed as dist
@@ -250,11 +272,12 @@ def _rank_sinks(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
-        tiles = DistributedTiles(LocationHash2D(**grid), (2, 1), halo_cells=1, device=0)
-        _sink_scene(tiles)
+        side, dt = _TWO_RANK_GRID[kind]
+        grid = dict(width=side, height=side, cell_size=2.0, offset=(0.0, 0.0))
+        tiles = DistributedTiles(LocationHash2D(**grid), layout, halo_cells=2, device=0)
+        _two_rank_scene(kind, tiles)
         for k in range(400):
-            tiles.step(0.05, report=(k in (150, 151)))  # mostly the device-side spawn path
+            tiles.step(dt, report=(k in (150, 151)))  # mostly the device-side spawn path
         mine = tiles.read_agents()
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -266,26 +289,31 @@ def _rank_sinks(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path):
+@pytest.mark.parametrize("kind,layout,port", [("sinks", (2, 1), 29723), ("sinks", (1, 2), 29724),
+                                              ("routes", (1, 2), 29725), ("random", (2, 1), 29726)])
+def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path, kind, layout, port):
     """One rank per tile: the spawn flags are all-reduced between the ranks (on the device path
-    through a device tensor), ids follow the global sink order; same bits as one engine."""
+    through a device tensor), ids follow the global sink order; same bits as one engine.  Lanes
+    of constant-velocity walkers, route followers (their state travels in the halo records), a
+    random scene; cut along either axis."""
     import pickle
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = str(tmp_path / "sinks.pkl")
-    procs = [ctx.Process(target=_rank_sinks, args=(r, 2, 29723, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_sinks, args=(r, 2, port, out, kind, layout)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
     both = pickle.load(open(out, "rb"))
-    single = Simulation(LocationHash2D(60.0, 60.0, 2.0, (0.0, 0.0)))
-    _sink_scene(single)
+    side, dt = _TWO_RANK_GRID[kind]
+    single = Simulation(LocationHash2D(side, side, 2.0, (0.0, 0.0)))
+    _two_rank_scene(kind, single)
     for _ in range(400):
-        single.step(0.05, report=False)
+        single.step(dt, report=False)
     a = single.read_agents()
-    assert len(a) > 300 and a.tobytes() == both.tobytes()
+    assert len(a) > 50 and a.tobytes() == both.tobytes()
 
 
 def _rank_nccl_single(port, out_path):
