@@ -1055,3 +1055,41 @@ def test_random_removals_and_queries_between_steps_match_the_oracle(seed):
     a, b = sims[0].read_agents(), sims[1].read_agents()
     assert (a["id"] == b["id"]).all() and (a["next_waypoint"] == b["next_waypoint"]).all()
     assert len(a) == 0 or max_rel_err(a, b, 80.0) <= 1e-4
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_planner_groups_match_oracle_and_each_other(seed):
+    """Two to six groups in one crowd, each with its own Zanlungo parameters (scale, force
+    distance, mass, radius) or no local planner, stub or id-parity high-level plans, its own
+    eyesight: the per-group table of the kernels.  Tiled and gather kernels: the same bits; the
+    f64 oracle: within the stated tolerance."""
+    rng = np.random.default_rng(6100 + seed)
+    grid, pts, eyesight, speed, spacing = _fuzz_case(6000 + seed)
+    r0 = min(0.2, 0.45 * spacing)
+    n_groups = int(rng.integers(2, 7))
+    parts = np.split(np.arange(len(pts)), np.sort(rng.integers(0, len(pts), size=n_groups - 1)))
+    specs = []
+    for _ in range(n_groups):
+        lp = None if rng.random() < 0.2 else (float(rng.uniform(0.5, 2.0)), 1.0, 0.0, float(rng.uniform(1.5, 3.0)) * r0,
+                                              float(rng.uniform(1.0, 4.0)), float(rng.uniform(0.6, 1.0)) * r0)
+        hl = (("stub", (float(rng.uniform(-1, 1)) * speed, float(rng.uniform(-1, 1)) * speed)) if rng.random() < 0.6
+              else ("parity", (speed, 0.3 * speed)))
+        specs.append((lp, hl, float(eyesight * rng.uniform(0.5, 1.0))))
+    outs = []
+    for cls, flags in ((Simulation, 1), (Simulation, 2), (OracleSimulation, None)):
+        sim = cls(LocationHash2D(**grid), flags=flags) if flags else cls(LocationHash2D(**grid))
+        for idx, (lp, hl, eye) in zip(parts, specs):
+            if len(idx):
+                sim.add_agents(pts[idx], StubHighLevelPlan(hl[1]) if hl[0] == "stub" else IdParityHighLevelPlan(hl[1]),
+                               NoLocalPlan() if lp is None else Zanlungo(*lp), eye)
+        for _ in range(4):
+            sim.step(0.05)
+        outs.append((sim.read_agents(), sim.last_report))
+    (a, ra), (b, rb), (c, rc) = outs
+    assert a.tobytes() == b.tobytes() and ra["n_tti_zero"] == rc["n_tti_zero"]
+    ok = np.isfinite(c["x"]) & np.isfinite(a["x"])
+    assert ok.mean() > 0.99
+    L = max(grid["width"], grid["height"])
+    dv = np.hypot(a["vx"] - c["vx"], a["vy"] - c["vy"])[ok]
+    vmax = max(np.hypot(c["vx"], c["vy"])[ok].max(), speed)
+    assert np.hypot(a["x"] - c["x"], a["y"] - c["y"])[ok].max() / L <= 1e-4 and np.quantile(dv, 0.999) <= 1e-4 * vmax
