@@ -509,6 +509,40 @@ def test_random_meshes_match_the_single_engine(seed):
         assert len(a) == len(b) == n and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("report", [True, False])
+def test_an_agent_spawned_next_to_a_cut_is_seen_across_it_at_once(report):
+    """lib.rs:199-254 then :259: the spawn phase inserts the new agent into the index before the
+    update loop, so it is a neighbour from its first step on.  A tile's halo exchange runs before
+    the spawn phase; a source in the ghost ring therefore spawns a ghost on this side as well
+    (every tile knows the combined spawn flags and the ids).  Walkers stand 0.5 m from a source
+    on the other side of the cut; the host and the device form of the spawn phase."""
+    from rmf_crowdsim_amd import MonotonicCrowd, SourceSink
+    grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    watchers = np.array([(19.6, 10.0), (19.5, 10.7), (19.7, 9.4), (20.4, 30.3), (20.2, 29.5)])
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 1), halo_cells=1)
+    for t in (single, mesh):
+        t.add_agents(watchers[:3], StubHighLevelPlan((0.05, 0.0)), lp, 2.0)   # walking towards the sources
+        t.add_agents(watchers[3:], StubHighLevelPlan((-0.05, 0.0)), lp, 2.0)
+        # the spawned walkers leave at 1 m/s (no local planner), so each source is free again
+        # after 8 steps and spawns while the watchers are under way (at rest nobody feels anybody)
+        t.add_source_sink(SourceSink((20.1, 10.0), 1.0, MonotonicCrowd(20.0), StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(),
+                                     [(35.0, 10.0)], False, 2.0))   # source owned by the upper tile
+        t.add_source_sink(SourceSink((19.9, 30.0), 1.0, MonotonicCrowd(20.0), StubHighLevelPlan((-1.0, 0.0)), NoLocalPlan(),
+                                     [(5.0, 30.0)], False, 2.0))    # ... by the lower tile
+    felt = False
+    for _ in range(20):
+        single.step(0.05, report=report)
+        mesh.step(0.05, report=report)
+        v = single.read_agents()["vx"][:5]
+        felt = felt or bool(np.abs(np.abs(v) - 0.05).max() > 1e-6)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) == 11 and a.tobytes() == b.tobytes()
+    # (the watchers did feel the newcomers, who have right of way over them: larger ids)
+    assert felt and np.isfinite(a["vx"]).all()
+
+
 def _random_sink_scene(t, rng_seed):
     from rmf_crowdsim_amd import MonotonicCrowd, SeededPoissonCrowd, SourceSink
     rng = np.random.default_rng(rng_seed)
