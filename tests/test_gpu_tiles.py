@@ -543,6 +543,31 @@ def test_an_agent_spawned_next_to_a_cut_is_seen_across_it_at_once(report):
     assert felt and np.isfinite(a["vx"]).all()
 
 
+@pytest.mark.parametrize("seed,tiles,phases", [(3, (4, 2), 1), (3, (2, 2), 2), (1, (1, 3), 1), (5, (1, 2), 2)])
+def test_creeping_crowd_with_random_source_sinks_across_tiles(seed, tiles, phases):
+    """30,000 creeping agents (the LDS-tiled kernel on every tile) and 40 source-sinks anywhere,
+    inside the crowd and next to the cuts: the scene that showed the spawn-next-to-a-cut defect."""
+    from rmf_crowdsim_amd import SeededPoissonCrowd, SourceSink
+    n = 30000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=seed, cell_size=2.0, margin=20.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1, phases=phases)
+    for t in (single, mesh):
+        scenes.add_counterflow(t, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+        rng = np.random.default_rng(55 + seed)
+        for k in range(40):
+            src, dst = rng.uniform(4.0, grid["width"] - 4.0, size=2), rng.uniform(4.0, grid["width"] - 4.0, size=2)
+            v = (dst - src) / max(np.linalg.norm(dst - src), 1e-9) * 0.002
+            t.add_source_sink(SourceSink(tuple(src), 1.0, SeededPoissonCrowd(3.0, 700 + k), StubHighLevelPlan(tuple(v)), lp,
+                                         [tuple(dst)], False, 2.0))
+    for k in range(40):
+        single.step(0.05, report=k in (10, 11, 30))
+        mesh.step(0.05, report=k in (10, 11, 30))
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > n + 5 and np.isfinite(a["x"]).all() and a.tobytes() == b.tobytes()
+
+
 def _random_sink_scene(t, rng_seed):
     from rmf_crowdsim_amd import MonotonicCrowd, SeededPoissonCrowd, SourceSink
     rng = np.random.default_rng(rng_seed)
