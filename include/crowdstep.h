@@ -267,7 +267,9 @@ int cs_snapshot_acquire(cs_engine*, int wait, const cs_snapshot_record** out,
                         size_t* n, uint64_t* step_index);
 /* SpatialIndex::get_neighbours_in_radius                location_hash_2d.rs:240-258
  * returns the full count; writes min(count, cap) ids in reference cell order
- * (x-major, y-minor) with ascending id inside a cell. */
+ * (x-major, y-minor) with ascending id inside a cell.  As in the reference, a rectangle wider
+ * than the grid lists the members of a cell once per row through which it reaches the cell
+ * (y runs past the row stride, :74-85): an id can come back several times. */
 size_t cs_query_radius(cs_engine*, double radius, double x, double y,
                        uint64_t* out_ids, size_t cap);
 /* SpatialIndex::get_nearest_neighbours                  location_hash_2d.rs:151-238 */

@@ -392,8 +392,13 @@ void cs_event_recording(cs_engine* e, int on) {
 
 // Radius query on the device index: ids in reference cell order (x-major, y-minor, ascending id
 // inside a cell) and their squared distances.  Returns the full count.
+// `every_alias`: walk the whole rectangle the reference walks.  A rectangle wider than the grid
+// reaches a cell of row R once through every row <= R (y runs past the row stride into the next
+// rows, location_hash_2d.rs:74-85), and the reference lists its members every time; the public
+// query reproduces that, the k-NN search (which removes duplicates anyway) visits at most two
+// rows' worth of y.
 static size_t radius_query(cs_engine* e, double radius, double x, double y, std::vector<uint32_t>* ids,
-                           std::vector<float>* d2, size_t cap) {
+                           std::vector<float>* d2, size_t cap, bool every_alias) {
   if (e->tile) {
     e->error = "spatial queries are not available on a tile engine";
     return 0;
@@ -411,7 +416,8 @@ static size_t radius_query(cs_engine* e, double radius, double x, double y, std:
   long long lx = fl(x - radius, e->grid.offset_x), hx = fl(x + radius, e->grid.offset_x);
   long long ly = fl(y - radius, e->grid.offset_y), hy = fl(y + radius, e->grid.offset_y);
   lx = std::max(lx, -1ll); ly = std::max(ly, -1ll);
-  hx = std::min(hx, (long long)e->nx); hy = std::min(hy, (long long)e->nx * 2);
+  hx = std::min(hx, (long long)(e->ncells / std::max<uint64_t>(e->nx, 1)));
+  hy = std::min(hy, every_alias ? (long long)e->ncells : (long long)e->nx * 2);
   // query point relative to a reference cell: the cell of the point clamped into the grid
   long long qx = std::min(std::max(fl(x, e->grid.offset_x), 0ll), (long long)e->nx - 1);
   long long qy = std::min(std::max(fl(y, e->grid.offset_y), 0ll), (long long)e->nx - 1);
@@ -456,7 +462,7 @@ size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t
   hipSetDevice(e->device);
   std::vector<uint32_t> ids;
   std::vector<float> d2;
-  size_t cnt = radius_query(e, radius, x, y, &ids, &d2, cap);
+  size_t cnt = radius_query(e, radius, x, y, &ids, &d2, cap, true);
   for (size_t i = 0; i < ids.size() && i < cap; ++i) out_ids[i] = ids[i];
   return cnt;
 }
@@ -476,7 +482,7 @@ size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_id
   std::vector<std::pair<float, uint32_t>> by_dist;
   double r = e->grid.cell_size;
   for (;;) {
-    radius_query(e, r, x, y, &ids, &d2, (size_t)1 << 22);
+    radius_query(e, r, x, y, &ids, &d2, (size_t)1 << 22, false);
     // a window wider than the grid visits aliased cells twice (row stride nx on both axes,
     // location_hash_2d.rs:59), so count distinct ids
     by_dist.resize(ids.size());

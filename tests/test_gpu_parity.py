@@ -1093,3 +1093,68 @@ def test_random_planner_groups_match_oracle_and_each_other(seed):
     dv = np.hypot(a["vx"] - c["vx"], a["vy"] - c["vy"])[ok]
     vmax = max(np.hypot(c["vx"], c["vy"])[ok].max(), speed)
     assert np.hypot(a["x"] - c["x"], a["y"] - c["y"])[ok].max() / L <= 1e-4 and np.quantile(dv, 0.999) <= 1e-4 * vmax
+
+
+def _api_sequence(cls, seed):
+    rng = np.random.default_rng(seed)
+    log = []
+    def do(name, fn):
+        try:
+            r = fn()
+            log.append((name, "ok", r))
+        except CrowdSimError as e:
+            log.append((name, "err", str(e)))
+    cell = float(rng.choice([1.0, 2.0, 3.0]))
+    w, h = float(rng.choice([20.0, 40.0, 41.5])), float(rng.choice([20.0, 30.0, 40.0]))
+    if h > w: w, h = h, w
+    off = (float(rng.uniform(-10, 10)), float(rng.uniform(-10, 10)))
+    sim = cls(LocationHash2D(w, h, cell, off))
+    lp = NoLocalPlan() if rng.random() < 0.5 else Zanlungo(0.02, 1.0, 0.0, 0.4, 2.0, 0.2)
+    for step in range(40):
+        op = rng.random()
+        if op < 0.25:
+            n = int(rng.choice([0, 1, 5, 40]))
+            kind = rng.random()
+            if kind < 0.6: pts = rng.uniform(2.0, min(w, h) - 2.0, size=(n, 2)) + np.array(off)
+            elif kind < 0.8: pts = rng.uniform(-5.0, max(w, h) + 5.0, size=(n, 2)) + np.array(off)   # some outside
+            else: pts = np.full((n, 2), np.nan) if rng.random() < 0.3 else rng.uniform(2.0, 6.0, size=(n, 2)) + np.array(off)
+            v = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
+            eye = float(rng.choice([0.0, 0.5, 2.0, 5.0, 30.0]))
+            do("add", lambda: list(sim.add_agents(pts, StubHighLevelPlan(v), lp, eye)))
+        elif op < 0.35:
+            do("remove", lambda: sim.remove_agents(int(rng.integers(0, 200))))
+        elif op < 0.45:
+            q = rng.uniform(-20, 60, size=2) + np.array(off); r = float(rng.choice([-1.0, 0.0, 0.5, 3.0, 1e3]))
+            do("radius", lambda: sorted(sim.get_neighbours_in_radius(r, q)))
+        elif op < 0.5:
+            do("sink", lambda: sim.add_source_sink(SourceSink(tuple(rng.uniform(2.0, h - 2.0, size=2) + np.array(off)), 0.7, MonotonicCrowd(float(rng.choice([0.0, 5.0, 30.0]))), StubHighLevelPlan((0.5, 0.2)), lp, [tuple(rng.uniform(2.0, h - 2.0, size=2) + np.array(off))], bool(rng.random() < 0.3), 2.0)))
+        elif op < 0.55:
+            do("rmsink", lambda: sim.remove_source_sink(int(rng.integers(0, 6))))
+        else:
+            dt = float(rng.choice([0.0, 0.05, 0.1, 0.1, 0.1, 1.0, -0.1]))
+            do("step", lambda: (sim.step(dt), len(sim))[1])
+        do("len", lambda: len(sim))
+    try:
+        a = sim.read_agents()
+        log.append(("final", "ok", (a["id"].tolist(), np.round(a["x"], 3).tolist(), np.round(a["y"], 3).tolist())))
+    except CrowdSimError as e:
+        log.append(("final", "err", str(e)))
+    return log
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_api_sequences_give_the_oracle_s_results_and_errors(seed):
+    """Forty random calls per run, sensible or not: adds (empty, outside the grid, NaN, eyesight 0
+    to 30 on a 20 m grid), removals of ids that may not exist, radius queries anywhere (radius
+    negative, zero, or wider than the grid: the reference then lists a cell's members once per
+    row through which it reaches the cell), source-sinks with rate 0 to 30, sink removals, steps
+    with dt 0, negative, 1 s.  Every call returns what the oracle returns or fails as it fails."""
+    la, lb = _api_sequence(Simulation, 12000 + seed), _api_sequence(OracleSimulation, 12000 + seed)
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x[0] == "add" and x[1] == "err":
+            break  # the reference keeps the agent it could not index (and fails every later step); the engine drops it
+        if x != y and x[0] == "final" and x[1] == y[1] == "ok" and x[2][0] == y[2][0]:
+            assert np.allclose(x[2][1], y[2][1], atol=2e-3, equal_nan=True)
+            assert np.allclose(x[2][2], y[2][2], atol=2e-3, equal_nan=True)
+            continue
+        assert x == y, f"call {i}: engine {str(x)[:200]} | oracle {str(y)[:200]}"
