@@ -278,6 +278,10 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
         _two_rank_scene(kind, tiles)
         for k in range(400):
             tiles.step(dt, report=(k in (150, 151)))  # mostly the device-side spawn path
+            if k == 200:  # a collective removal: the youngest walker, whichever rank holds it
+                ids = [None] * world
+                dist.all_gather_object(ids, [int(i) for i in tiles.read_agents()["id"]])
+                tiles.remove_agents(max(i for part in ids for i in part))
         mine = tiles.read_agents()
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -310,8 +314,10 @@ def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path, kind, layout, p
     side, dt = _TWO_RANK_GRID[kind]
     single = Simulation(LocationHash2D(side, side, 2.0, (0.0, 0.0)))
     _two_rank_scene(kind, single)
-    for _ in range(400):
+    for k in range(400):
         single.step(dt, report=False)
+        if k == 200:
+            single.remove_agents(int(single.read_agents()["id"].max()))
     a = single.read_agents()
     assert len(a) > 50 and a.tobytes() == both.tobytes()
 
