@@ -637,6 +637,66 @@ def test_random_source_sinks_engine_oracle_and_mesh_agree(seed):
     assert len(a) == 0 or max_rel_err(a[ok], b[ok], 80.0) <= 1e-4
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed):
+    """Sixty random calls per run on a mesh (random shape, halo, even or weighted cuts, either
+    exchange schedule) and on one engine: agents added in mid-run (some hugging the cuts),
+    removals, source-sinks added in mid-run, steps with and without a report; kinematic walkers or
+    the social force on a jittered lattice.  The same ids come back from every add, and the same
+    bits at the end."""
+    import math
+    from rmf_crowdsim_amd import CrowdSimError, SeededPoissonCrowd, SourceSink
+    rng = np.random.default_rng(15000 + seed)
+    cell = float(rng.choice([1.0, 2.0, 2.5])); side = float(rng.choice([40.0, 60.0, 80.0]))
+    grid = dict(width=side, height=side, cell_size=cell, offset=(float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))))
+    off = np.array(grid["offset"]); eyes = float(rng.choice([1.0, 2.0, 3.0])); halo = math.ceil(eyes / cell - 1e-9)
+    tiles = [(2, 2), (3, 1), (1, 3), (2, 3), (4, 2), (1, 2)][int(rng.integers(0, 6))]
+    ncell = int(side / cell)
+    if min(ncell // tiles[0], ncell // tiles[1]) < 2 * halo + 2: tiles = (2, 1)
+    w = rng.normal(side / 2, side / 6, size=(2000, 2)).clip(1, side - 1) + off if rng.random() < 0.5 else None
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, weights=w, phases=int(rng.choice([1, 2])))
+    kin = rng.random() < 0.5
+    lp = NoLocalPlan() if kin else Zanlungo(*scenes.METRIC_ZANLUNGO)
+    speed, dt = (1.0, 0.1) if kin else (0.002, 0.05)
+    lattice = scenes.jittered_lattice(4000, 0.6, (8.0 + off[0], 8.0 + off[1]), 0.15, seed)   # no overlaps for the social force
+    lattice = lattice[(lattice[:, 0] < side - 8 + off[0]) & (lattice[:, 1] < side - 8 + off[1])]
+    used = 0
+    try:
+        for k in range(60):
+            op = rng.random()
+            if op < 0.2:
+                n = int(rng.choice([1, 10, 200]))
+                if kin:
+                    pts = rng.uniform(8.0, side - 8.0, size=(n, 2)) + off
+                    if rng.random() < 0.3: pts[:, 0] = np.round((pts[:, 0] - off[0]) / cell) * cell + off[0] + rng.uniform(-0.05, 0.05, size=n)
+                else:
+                    pts = lattice[used:used + n]; used += n
+                    if not len(pts): continue
+                v = (float(rng.uniform(-1, 1)) * speed, float(rng.uniform(-1, 1)) * speed)
+                ia = single.add_agents(pts, StubHighLevelPlan(v), lp, eyes); ib = mesh.add_agents(pts, StubHighLevelPlan(v), lp, eyes)
+                assert list(ia) == list(ib), "ids"
+            elif op < 0.3:
+                if len(single):
+                    a = single.read_agents(); vic = int(a["id"][int(rng.integers(0, len(a)))])
+                    single.remove_agents(vic); mesh.remove_agents(vic)
+            elif op < 0.35 and kin:
+                src = rng.uniform(8.0, side - 8.0, size=2) + off; dst = rng.uniform(8.0, side - 8.0, size=2) + off
+                d = dst - src; v = d / max(np.linalg.norm(d), 1e-9) * speed
+                for t in (single, mesh):
+                    t.add_source_sink(SourceSink(tuple(src), 0.8, SeededPoissonCrowd(4.0, 100 + k), StubHighLevelPlan(tuple(v)), lp, [tuple(dst)], False, eyes))
+            else:
+                rep = bool(rng.random() < 0.3)
+                single.step(dt, report=rep); mesh.step(dt, report=rep)
+    except CrowdSimError:
+        pass  # some call met a failed step: sorted out below
+    for e in [single] + mesh.engines:
+        e.synchronize()  # nothing here leaves the model's finite range
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) == len(b) and a.tobytes() == b.tobytes()
+
+
+
 def _route_scene(target, lp):
     """Sixteen lanes whose walkers follow host-planned doglegs (RouteFollower) across the cuts."""
     from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
