@@ -309,6 +309,9 @@ void cs_profile_reset(cs_engine*);
 enum { CS_DIR_XLO = 0, CS_DIR_XHI = 1, CS_DIR_YLO = 2, CS_DIR_YHI = 3,
        /* the diagonal neighbours, for the one-phase exchange (cs_halo_pack_all) */
        CS_DIR_XLO_YLO = 4, CS_DIR_XLO_YHI = 5, CS_DIR_XHI_YLO = 6, CS_DIR_XHI_YHI = 7 };
+/* A record: cell-relative offset and velocity (4 x f32), id, group | next_waypoint << 16, the
+ * GLOBAL cell (x row, y column; 2 x u32), the route follower's state and a reserved word.  The
+ * layout is the engine's business: the transport moves bytes. */
 #define CS_HALO_RECORD_BYTES 40u
 /* Caller-provided device buffers (e.g. torch CUDA tensors) of
  * (capacity_records + 1) * CS_HALO_RECORD_BYTES bytes: record 0 is the header
