@@ -384,6 +384,10 @@ class DistributedTiles(_TileBase):
         self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
         return self.sim.add_source_sink(source_sink)
 
+    def add_event_listener(self, listener):
+        """Events of this rank's tile (spawns of the sinks it owns, removals of agents it holds)."""
+        return self.sim.add_event_listener(listener)
+
     def remove_source_sink(self, handle):
         self.sim.remove_source_sink(handle)
 
