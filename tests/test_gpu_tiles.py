@@ -276,6 +276,11 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
         grid = dict(width=side, height=side, cell_size=2.0, offset=(0.0, 0.0))
         tiles = DistributedTiles(LocationHash2D(**grid), layout, halo_cells=2, device=0)
         _two_rank_scene(kind, tiles)
+        listener = None
+        if kind == "sinks" and layout == (1, 2):  # with a listener every spawn phase goes through the host
+            from test_oracle_reference_kats import MockEventListener
+            listener = MockEventListener()
+            tiles.add_event_listener(listener)
         for k in range(400):
             tiles.step(dt, report=(k in (150, 151)))  # mostly the device-side spawn path
             if k == 200:  # a collective removal: the youngest walker, whichever rank holds it
@@ -285,10 +290,14 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
         mine = tiles.read_agents()
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
+        events = [None] * world
+        dist.all_gather_object(events, (listener.added, listener.removed) if listener else None)
         if rank == 0:
             both = np.concatenate(gathered)
             with open(out_path, "wb") as f:
                 pickle.dump(both[np.argsort(both["id"], kind="stable")], f)
+                if listener:
+                    pickle.dump((sorted(i for e in events for i in e[0]), sorted(i for e in events for i in e[1])), f)
     finally:
         dist.destroy_process_group()
 
@@ -310,16 +319,24 @@ def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path, kind, layout, p
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    both = pickle.load(open(out, "rb"))
+    with open(out, "rb") as f:
+        both = pickle.load(f)
+        events = pickle.load(f) if kind == "sinks" and layout == (1, 2) else None
     side, dt = _TWO_RANK_GRID[kind]
     single = Simulation(LocationHash2D(side, side, 2.0, (0.0, 0.0)))
     _two_rank_scene(kind, single)
+    if events is not None:
+        from test_oracle_reference_kats import MockEventListener
+        heard = MockEventListener()
+        single.add_event_listener(heard)
     for k in range(400):
         single.step(dt, report=False)
         if k == 200:
             single.remove_agents(int(single.read_agents()["id"].max()))
     a = single.read_agents()
     assert len(a) > 50 and a.tobytes() == both.tobytes()
+    if events is not None:  # every spawn and removal was heard by exactly one rank
+        assert events == (sorted(heard.added), sorted(heard.removed)) and len(events[0]) > 300
 
 
 def _rank_nccl_single(port, out_path):
