@@ -225,6 +225,9 @@ int cs_remove_agent(cs_engine*, uint64_t id);
  * is called once per tile, in registration order) so that every tile numbers routes alike. */
 uint32_t cs_add_source_sink(cs_engine*, const cs_source_sink_desc*);
 void cs_remove_source_sink(cs_engine*, uint32_t handle);
+/* Number of source-sink handles ever handed out (registry.rs:16-21: ids only grow; a removed
+ * sink keeps its slot).  cs_spawn_probe / cs_spawn_commit take one flag per SLOT. */
+size_t cs_source_sink_slots(cs_engine*);
 
 /* ---- the hot path ------------------------------------------------------ */
 /* Simulation::step(dur), dt_seconds = dur.as_secs_f64()          lib.rs:195-383

@@ -892,6 +892,7 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   return h;
 }
 void cs_remove_source_sink(cs_engine* e, uint32_t handle) { e->source_sinks.erase(handle); }
+size_t cs_source_sink_slots(cs_engine* e) { return e->next_sink_handle; }
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
   const int rc = e->step(dt_seconds, report);
@@ -1026,6 +1027,47 @@ double oracle_time_to_collision(double agent_radius, double rvx, double rvy, dou
   z.agent_mass = 1;
   z.agent_radius = (Real)agent_radius;
   return (double)z.time_to_collision(V2{(Real)rvx, (Real)rvy}, V2{(Real)rpx, (Real)rpy});
+}
+
+// Oracle-only probes for tests/test_zanlungo_restatement.py: the planner on explicit Agent
+// records, INCLUDING a neighbour's preferred_vel (always (0,0) inside Simulation::step,
+// lib.rs:140,261,271, so the moving-neighbour branch zanlungo.rs:126-139 is reachable only here).
+// rec = {id, px, py, vx, vy, pref_x, pref_y}; params = Zanlungo::new's six arguments in order.
+static Zanlungo probe_planner(const double* params) {
+  Zanlungo z;
+  z.agent_scale = (Real)params[0];
+  z.obstacle_scale = (Real)params[1];
+  z.reaction_time = (Real)params[2];
+  z.force_distance = (Real)params[3];
+  z.agent_mass = (Real)params[4];
+  z.agent_radius = (Real)params[5];
+  return z;
+}
+static Agent probe_agent(const double* rec) {
+  Agent a = Agent{};
+  a.agent_id = (uint64_t)rec[0];
+  a.position = {(Real)rec[1], (Real)rec[2]};
+  a.velocity = {(Real)rec[3], (Real)rec[4]};
+  a.preferred_vel = {(Real)rec[5], (Real)rec[6]};
+  return a;
+}
+void oracle_zanlungo_pair_force(const double* params, const double* me, const double* other, double t_i,
+                                double* out_xy) {
+  const Zanlungo z = probe_planner(params);
+  const V2 f = z.compute_agent_force(probe_agent(me), probe_agent(other), (Real)t_i);
+  out_xy[0] = (double)f.x;
+  out_xy[1] = (double)f.y;
+}
+double oracle_zanlungo_desired_velocity(const double* params, const double* me, const double* others,
+                                        uint64_t n_others, double rec_x, double rec_y, double* out_xy) {
+  const Zanlungo z = probe_planner(params);
+  std::vector<Agent> nearby;
+  for (uint64_t k = 0; k < n_others; ++k) nearby.push_back(probe_agent(others + 7 * k));
+  const Agent a = probe_agent(me);
+  const V2 v = z.get_desired_velocity(a, nearby, V2{(Real)rec_x, (Real)rec_y}, nullptr);
+  out_xy[0] = (double)v.x;
+  out_xy[1] = (double)v.y;
+  return (double)z.compute_tti(a, nearby);
 }
 
 // SpatialIndex::add_or_update / remove_agent on the engine's index without

@@ -68,7 +68,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_state_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -243,37 +243,48 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
   return e->add_agents(xy, n, g, UINT32_MAX, out_ids);
 }
 
-// Simulation::remove_agents, lib.rs:176-192
+// Simulation::remove_agents, lib.rs:176-192.  0 = removed, 2 = nobody here has this id (on a tile:
+// another tile may), anything else = the engine's own failure (poisoned, HIP error).
 int cs_remove_agent(cs_engine* e, uint64_t id) {
   hipSetDevice(e->device);
   if (int rc = e->refresh_counts()) return rc;
-  cs_engine::HostState h;
-  if (int rc = e->download(&h)) return rc;
-  for (uint32_t i = 0; i < e->n_slots; ++i) {
-    if (h.cell[i] == CS_INVALID_CELL || h.id[i] != id) continue;
-    uint32_t inv = CS_INVALID_CELL;
-    if (hipMemcpy(e->buf[e->cur].cell + i, &inv, sizeof inv, hipMemcpyHostToDevice) != hipSuccess) {
+  uint32_t found[2] = {0xFFFFFFFFu, 0u};
+  if (id < 0xFFFFFFFFull && e->n_slots) {
+    if (!e->find_dev && hipMalloc(&e->find_dev, 2 * sizeof(uint32_t)) != hipSuccess) {
       e->error = "HIP error while removing an agent";
       return 90;
     }
-    const HostGroup& g = e->groups[h.meta[i] & 0xFFFFu];
-    const cs_hlp_desc& p = e->hlps[g.hlp];
-    if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, id);
-    e->sorted = false;
-    e->hist_valid = false;
-    e->occ_valid = false;
-    e->n_alive_host -= 1;
-    cs_event ev;
-    ev.kind = CS_EVENT_DESTROYED;
-    ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
-    ev.id = id;
-    ev.x = ev.y = 0;
-    if (e->record_events) e->events.push_back(ev);
-    return 0;
+    bool ok = hipMemcpyAsync(e->find_dev, found, sizeof found, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+    hipLaunchKernelGGL(k_remove_by_id, dim3((e->n_slots + 255u) / 256u), dim3(256), 0, e->stream, e->buf[e->cur],
+                       e->n_slots, e->ctr, e->gdev.tile, (uint32_t)id, e->find_dev);
+    ok = ok && hipMemcpyAsync(found, e->find_dev, sizeof found, hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipStreamSynchronize(e->stream) == hipSuccess;
+    if (!ok) {
+      e->error = "HIP error while removing an agent";
+      return 90;
+    }
   }
-  e->error = "unknown agent id";
-  return 2;
+  if (found[0] == 0xFFFFFFFFu) {
+    e->error = "unknown agent id";
+    return 2;
+  }
+  const HostGroup& g = e->groups[found[1] & 0xFFFFu];
+  const cs_hlp_desc& p = e->hlps[g.hlp];
+  if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, id);
+  e->sorted = false;
+  e->hist_valid = false;
+  e->occ_valid = false;
+  e->n_alive_host -= 1;
+  cs_event ev;
+  ev.kind = CS_EVENT_DESTROYED;
+  ev.source_sink = g.sink >= 0 ? (uint32_t)g.sink : UINT32_MAX;
+  ev.id = id;
+  ev.x = ev.y = 0;
+  if (e->record_events) e->events.push_back(ev);
+  return 0;
 }
+
+size_t cs_source_sink_slots(cs_engine* e) { return e->sinks.size(); }
 
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   if (e->groups.size() + 1 >= CS_MAX_GROUPS || d->n_waypoints == 0 || d->n_waypoints > 65535) {

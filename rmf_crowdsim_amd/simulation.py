@@ -539,12 +539,30 @@ class Simulation:
     def spawn_probe(self, dur):
         """Tile engines: which of MY source-sinks would spawn this step (uint8 flag per sink)."""
         dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
-        flags = np.zeros(max(len(self._source_sinks), 1), dtype=np.uint8)
+        # one flag per sink SLOT: a removed sink keeps its slot in the engine (registry.rs:16-21)
+        flags = np.zeros(max(int(self._lib.cs_source_sink_slots(self._engine)), 1), dtype=np.uint8)
         n = self._lib.cs_spawn_probe(self._engine, dt, flags.ctypes.data_as(C.POINTER(C.c_uint8)),
                                      len(flags))
         if n == C.c_size_t(-1).value:
             raise self._err()
         return flags[:n]
+
+    @property
+    def source_sink_slots(self):
+        """Source-sink handles handed out so far (removed sinks keep their slot)."""
+        return int(self._lib.cs_source_sink_slots(self._engine))
+
+    def remove_agent_here(self, agent):
+        """Tiles: remove `agent` if THIS engine holds it.  True = removed, False = not here;
+        any other failure of the engine (poisoned, HIP error) raises."""
+        rc = self._lib.cs_remove_agent(self._engine, int(agent))
+        if rc == 0:
+            self._agents_cache = None
+            self._dispatch_events()
+            return True
+        if rc == 2:
+            return False
+        raise self._err()
 
     def spawn_commit(self, flags):
         flags = np.ascontiguousarray(flags, dtype=np.uint8)

@@ -151,7 +151,7 @@ class LocalTileMesh(_TileBase):
     on the shared stream.  Same engine code path as one-rank-per-GPU."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device=0, capacity_records=None,
-                 density_per_cell=16.0, flags=0, weights=None, phases=1):
+                 density_per_cell=16.0, flags=0, weights=None, phases=1, capacity_hint=0):
         import torch
         self.torch = torch
         self.phases = int(phases)
@@ -166,8 +166,8 @@ class LocalTileMesh(_TileBase):
         stream = self.stream.cuda_stream
         self.engines, self.bufs = [], []
         for index in range(self.layout.n_tiles):
-            sim = self._make_engine(spatial_index, self.layout, index, halo_cells, device, stream, 0,
-                                    flags)
+            sim = self._make_engine(spatial_index, self.layout, index, halo_cells, device, stream,
+                                    capacity_hint, flags)
             tx, ty = self.layout.coords(index)
             cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
             bufs = {}
@@ -208,9 +208,7 @@ class LocalTileMesh(_TileBase):
         """lib.rs:176-192.  Between steps every agent is held by exactly one tile (its owner)."""
         from .simulation import CrowdSimError
         for sim in self.engines:
-            if sim._lib.cs_remove_agent(sim._engine, int(agent)) == 0:
-                sim._agents_cache = None
-                sim._dispatch_events()
+            if sim.remove_agent_here(agent):  # an engine failure (not "not here") raises
                 return
         raise CrowdSimError("unknown agent id")
 
@@ -249,7 +247,7 @@ class LocalTileMesh(_TileBase):
         if getattr(self, "_has_sinks", False):
             if not report and not self._host_planner and not any(e.host_events_needed for e in self.engines):
                 # nobody on the host listens: flags stay on the device (cs_spawn_probe_dev / _commit_dev)
-                n = self._n_sinks
+                n = self.engines[0].source_sink_slots
                 with self.torch.cuda.stream(self.stream):
                     if getattr(self, "_flag_bufs", None) is None or self._flag_bufs[0].numel() < n:
                         dev = self.bufs_device
@@ -394,15 +392,20 @@ class DistributedTiles(_TileBase):
     def remove_agents(self, agent):
         """lib.rs:176-192 on every rank (collective): the owner removes, the others learn of it."""
         from .simulation import CrowdSimError
-        found = self.sim._lib.cs_remove_agent(self.sim._engine, int(agent)) == 0
-        if found:
-            self.sim._agents_cache = None
-            self.sim._dispatch_events()
-        flag = self.torch.tensor([1 if found else 0], dtype=self.torch.int32)
+        failure = None
+        try:
+            found = self.sim.remove_agent_here(agent)
+        except CrowdSimError as err:  # this rank's engine failed: still take part in the collective
+            found, failure = False, err
+        flag = self.torch.tensor([1 if found else 0, 1 if failure else 0], dtype=self.torch.int32)
         if self.dist.get_backend() == "nccl":
             flag = flag.to(self.stream.device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-        if int(flag.item()) == 0:
+        if failure is not None:
+            raise failure
+        if int(flag[1].item()):
+            raise CrowdSimError("remove_agents failed on another rank")
+        if int(flag[0].item()) == 0:
             raise CrowdSimError("unknown agent id")
 
     def step(self, dur, report=False):
@@ -417,29 +420,38 @@ class DistributedTiles(_TileBase):
                 exchange_all(self.dist, self.layout, self.index, self.bufs, self._op_cache)
                 self.sim.halo_unpack_all()
         if getattr(self, "_has_sinks", False):
-            # ids follow the global sink order: OR the per-tile spawn flags (one small all-reduce)
-            if not report and not self._host_planner and not self.sim.host_events_needed:
-                # flags stay on the device; nothing waits for the host
-                n = self._n_sinks
-                with self.torch.cuda.stream(self.stream):
-                    if getattr(self, "_flags_dev", None) is None or self._flags_dev.numel() < n:
-                        self._flags_dev = self.torch.zeros(max(n, 1), dtype=self.torch.int32,
-                                                           device=self.stream.device)
-                    self.sim.spawn_probe_dev(dur, self._flags_dev.data_ptr(), n)
-                    if self.dist.get_backend() == "nccl":
-                        self.dist.all_reduce(self._flags_dev, op=self.dist.ReduceOp.MAX)
-                    else:  # test transport: gloo moves host memory
-                        host = self._flags_dev.cpu()
-                        self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
-                        self._flags_dev.copy_(host)
-                    self.sim.spawn_commit_dev(self._flags_dev.data_ptr(), n)
-            else:
-                flags = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))
-                if self.dist.get_backend() == "nccl":
-                    flags = flags.cuda()
-                self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
-                self.sim.spawn_commit(flags.cpu().numpy().astype(np.uint8))
+            # Ids follow the global sink order: OR the per-tile spawn flags.  Whether a rank probes
+            # and commits through its host (listeners, host planners, a report) or keeps the flags
+            # on the device is that rank's own business; what the ranks share is ONE all-reduce of
+            # one int32 per sink slot, issued from this single place whichever path a rank takes,
+            # so the ranks cannot fall out of step with each other.
+            host_path = report or self._host_planner or self.sim.host_events_needed
+            n = self.sim.source_sink_slots
+            with self.torch.cuda.stream(self.stream):
+                if getattr(self, "_flags_dev", None) is None or self._flags_dev.numel() < n:
+                    self._flags_dev = self.torch.zeros(max(n, 1), dtype=self.torch.int32,
+                                                       device=self.stream.device)
+                flags = self._flags_dev[:max(n, 1)]
+                if host_path:
+                    mine = self.torch.from_numpy(self.sim.spawn_probe(dur).astype(np.int32))
+                    flags[:len(mine)].copy_(mine)
+                else:
+                    self.sim.spawn_probe_dev(dur, flags.data_ptr(), n)
+                self._allreduce_max(flags)
+                if host_path:
+                    self.sim.spawn_commit(flags[:n].cpu().numpy().astype(np.uint8))
+                else:
+                    self.sim.spawn_commit_dev(flags.data_ptr(), n)
         self.sim.step(dur, report=report)
+
+    def _allreduce_max(self, t):
+        """MAX over the ranks of a device tensor, on the engine's stream."""
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        else:  # test transport (ranks sharing one GPU): gloo moves host memory
+            host = t.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX)
+            t.copy_(host)
 
     def read_agents(self):
         return self.sim.read_agents()

@@ -35,6 +35,12 @@ def load_oracle(kind="f64"):
     lib.oracle_fast_steps.restype = ctypes.c_double
     lib.oracle_fast_steps.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
                                       [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int])
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.oracle_zanlungo_pair_force.restype = None
+    lib.oracle_zanlungo_pair_force.argtypes = [dp, dp, dp, ctypes.c_double, dp]
+    lib.oracle_zanlungo_desired_velocity.restype = ctypes.c_double
+    lib.oracle_zanlungo_desired_velocity.argtypes = [dp, dp, dp, ctypes.c_uint64, ctypes.c_double,
+                                                     ctypes.c_double, dp]
     _libs[kind] = lib
     return lib
 

@@ -1,0 +1,150 @@
+"""BASELINE.json configs[1], [3] and [4] at the sizes they are written with, on the device.
+
+configs[1] (100k agents on 200 x 200 m) is small enough for the f64 oracle (0.25 s per step), so it
+is compared with it directly, plus the three-way f32 / f64 split of SURVEY.md section 8d.  configs[3]
+(1M agents sustained by source-sinks) and configs[4] (4M agents, half of them in hotspots) are far
+beyond what the oracle steps in seconds: they are checked through properties that need no oracle run
+(the exact gather kernel, the LDS-tiled kernel and a tile mesh must give the same bits; nobody is
+lost, duplicated or non-finite; spawn and destroy counts add up).  configs[0] and [2] at their sizes:
+tests/test_gpu_parity.py::test_config1_256_agents_1000_steps,
+tests/test_gpu_tiles.py::test_full_size_crowd_invariants.
+"""
+import numpy as np
+import pytest
+
+from oracle_sim import OracleSimulation, OracleSimulationF32
+from rmf_crowdsim_amd import (LocationHash2D, MonotonicCrowd, Simulation, SourceSink, StubHighLevelPlan,
+                              Zanlungo, _abi, scenes)
+from rmf_crowdsim_amd.tiles import LocalTileMesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b, scale):
+    assert (a["id"] == b["id"]).all()
+    return float(np.hypot(a["x"] - b["x"], a["y"] - b["y"]).max() / scale)
+
+
+def test_config1_exact_size():
+    """configs[1] as written: 100,000 agents uniform on 200 x 200 m (2.5 / m^2), Zanlungo, cell 2 m,
+    eyesight 2 m, dt 0.05 s, one MI355X.  Engine vs f64 oracle over 8 steps (every step compared),
+    then the three-way split: engine (cell-relative f32) / oracle built in f32 / f64 oracle."""
+    n = 100_000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0)
+    assert abs(extent - 200.0) < 1.0  # 317 x 317 lattice sites, 0.632 m apart
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    sims = {}
+    for name, cls in (("gpu", Simulation), ("o32", OracleSimulationF32), ("o64", OracleSimulation)):
+        sims[name] = cls(LocationHash2D(**grid))
+        scenes.add_counterflow(sims[name], pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    worst = 0.0
+    for k in range(8):
+        for s in sims.values():
+            s.step(0.05)
+        a, b = sims["gpu"].read_agents(), sims["o64"].read_agents()
+        assert len(a) == n
+        worst = max(worst, _rel(a, b, extent))
+        assert sims["gpu"].last_report["n_tti_zero"] == sims["o64"].last_report["n_tti_zero"] == 0
+        assert sims["gpu"].last_report["n_nonfinite"] == 0
+    c = sims["o32"].read_agents()
+    e_gpu_64, e_32_64, e_gpu_32 = _rel(a, b, extent), _rel(c, b, extent), _rel(a, c, extent)
+    force = np.hypot(b["vx"], np.abs(b["vy"]) - scenes.CREEP_SPEED)
+    dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])
+    print(f"configs[1] 100k: worst |dp|/L over 8 steps {worst:.2e}; gpu-f64 {e_gpu_64:.2e}, f32-f64 {e_32_64:.2e}, "
+          f"gpu-f32 {e_gpu_32:.2e}; forced {float(np.mean(force > 0)):.3f}; |dv| p99.9/max|F| "
+          f"{float(np.quantile(dv, 0.999) / force.max()):.2e}")
+    assert worst <= 1e-4 and np.mean(force > 0) > 0.95
+    assert np.quantile(dv, 0.999) <= 2e-3 * force.max()
+    # the engine's cell-relative f32 must not be further from the f64 path than plain f32 is
+    assert e_gpu_64 <= max(e_32_64, 1e-7) * 1.5
+
+
+def _stream(target, lanes, lp, eyesight):
+    plans = {}
+    for src, dst, vel in lanes:
+        hlp = plans.setdefault(vel, StubHighLevelPlan(vel))
+        target.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False, eyesight))
+
+
+def test_config3_one_million_agents_sustained_by_source_sinks():
+    """configs[3] at full size: 25,000 source-sink lanes (16 m each, one agent released whenever the
+    source is free: lib.rs:212-217) fill up to ~1M walking agents (1.3 m/s); from then on every step
+    spawns and destroys thousands (per-step compaction).  The exact gather kernel, the tiled kernel
+    and a 1 x 1 tile mesh (the multi-GPU bookkeeping: device-side spawn flags, halo buffers) must
+    agree bit for bit; ids are unique, the population is conserved (alive = spawned - destroyed),
+    everyone alive is finite and inside its lane."""
+    lanes, grid, fill_steps = scenes.stream_lanes(1_000_000, cell_size=2.0)
+    assert len(lanes) == 25_000
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    steps = fill_steps + 40
+    runs = {}
+    for name in ("tiled", "gather", "mesh"):
+        if name == "mesh":
+            t = LocalTileMesh(LocationHash2D(**grid), (1, 1), halo_cells=1, capacity_hint=1_200_000)
+        else:
+            t = Simulation(LocationHash2D(**grid), flags=2 if name == "tiled" else 1, capacity_hint=1_200_000)
+        _stream(t, lanes, lp, 2.0)
+        spawned = destroyed = 0
+        for k in range(steps):
+            # the two engines report every step (host path: counts add up exactly); the mesh runs
+            # fire-and-forget (spawn flags and ids stay on the device)
+            t.step(0.05, report=name != "mesh")
+            if name != "mesh":
+                spawned += t.last_report["n_spawned"]
+                destroyed += t.last_report["n_destroyed"]
+        runs[name] = (t.read_agents(), spawned, destroyed, t)
+    a, spawned, destroyed, sim = runs["tiled"]
+    g, g_spawned, g_destroyed, _ = runs["gather"]
+    m = runs["mesh"][0]
+    print(f"configs[3]: {len(a)} agents alive after {steps} steps, {spawned} spawned, {destroyed} destroyed, "
+          f"last step +{sim.last_report['n_spawned']} -{sim.last_report['n_destroyed']}")
+    assert 800_000 < len(a) <= 1_050_000
+    assert sim.last_report["n_spawned"] > 1000 and sim.last_report["n_destroyed"] > 1000  # steady state
+    assert len(np.unique(a["id"])) == len(a)
+    assert a["id"].max() < spawned + 1 and spawned - destroyed == len(a)
+    assert (spawned, destroyed) == (g_spawned, g_destroyed)
+    assert a.tobytes() == g.tobytes() == m.tobytes()
+    assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
+    assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0
+    # walkers stay in their lanes (lanes are 1 m apart; the force is perpendicular but small here)
+    lane_x = np.array([l[0][0] for l in lanes])
+    nearest = np.abs(a["x"][:, None][:2000] - lane_x[None, :]).min(axis=1)
+    assert nearest.max() < 0.5
+
+
+def test_config4_four_million_agents_with_hotspots():
+    """configs[4] at full size: 4M agents, half a uniform background, half in Gaussian hotspots
+    (up to 4.9 agents/m^2: neighbour lists beyond 64 entries, windows walked in chunks).  Tiled
+    kernel = gather kernel = 4 x 2 tile mesh with weighted cuts, bit for bit; nobody lost,
+    duplicated or non-finite; nearly everybody feels a force."""
+    n = 4_000_000
+    pts, grid, extent, group = scenes.hotspot_crowd(n, seed=7, cell_size=2.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+
+    def run(target, steps=2):
+        scenes.add_counterflow(target, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+        for _ in range(steps):
+            target.step(0.05, report=False)
+        out = target.read_agents()
+        rep = None
+        if isinstance(target, Simulation):
+            target.step(0.05)
+            rep = dict(target.last_report)
+        return out, rep
+
+    tiled, rep = run(Simulation(LocationHash2D(**grid), flags=2 | _abi.CS_CFG_DENSE, capacity_hint=n + 1024))
+    gather, rep_g = run(Simulation(LocationHash2D(**grid), flags=1 | _abi.CS_CFG_DENSE, capacity_hint=n + 1024))
+    mesh_t = LocalTileMesh(LocationHash2D(**grid), (4, 2), halo_cells=1, density_per_cell=30.0,
+                           flags=_abi.CS_CFG_DENSE, weights=pts)
+    counts = mesh_t.layout.tile_counts(pts, LocationHash2D(**grid))
+    mesh, _ = run(mesh_t)
+    print(f"configs[4]: 4M agents, tiles {counts.reshape(-1).tolist()} (max/mean {counts.max() / counts.mean():.3f}), "
+          f"report {rep}")
+    assert len(tiled) == n and (tiled["id"] == np.arange(n)).all()
+    assert tiled.tobytes() == gather.tobytes()
+    assert tiled.tobytes() == mesh.tobytes()
+    assert np.isfinite(tiled["x"]).all() and np.isfinite(tiled["vx"]).all()
+    assert rep["n_agents"] == n and rep["n_tti_zero"] == rep_g["n_tti_zero"] == 0 and rep["n_nonfinite"] == 0
+    force = np.hypot(tiled["vx"], np.abs(tiled["vy"]) - scenes.CREEP_SPEED)
+    assert np.mean(force > 0) > 0.9
+    assert counts.max() / counts.mean() < 1.2

@@ -127,6 +127,37 @@ def test_kat_z3_overlap_nan_semantics():
     assert len(sim) == 2 and math.isnan(sim.agents[1].position[1])
 
 
+def test_reference_ttc_fixture_on_the_device():
+    """The reference's own time_to_collision fixture (zanlungo.rs:225-229: Zanlungo::new(1, 10, 0, 5,
+    0.1, 4), rel_vel (1,0), rel_pos (-10,0) => 6.0), reached on the DEVICE through the force it
+    sets: agent 0 at (10,0) walks at (-1,0) towards agent 1 resting at the origin, so t_i = 6 and
+    (closed form, zanlungo.rs:93-170 with weight 2) F = (0, 2*A*|v|/6 * exp(-(4 - 2*4)/5)), hence
+    v_y = F/m = (1/3) e^0.8 / 0.1.  The second fixture (:232-236, rel_pos (10,0) => +inf): the
+    same pair walking apart feels nothing."""
+    lp = Zanlungo(1.0, 10.0, 0.0, 5.0, 0.1, 4.0)
+    expect = (2.0 * 1.0 * 1.0 / 6.0) * math.exp(-(4.0 - 2.0 * 4.0) / 5.0) / 0.1
+    for cls in (Simulation, OracleSimulation):
+        sim = cls(LocationHash2D(200.0, 200.0, 20.0, (-100.0, -100.0)))
+        sim.add_agents([(10.5, 0.0)], StubHighLevelPlan((-1.0, 0.0)), lp, 30.0)
+        sim.add_agents([(0.0, 0.0)], StubHighLevelPlan((0.0, 0.0)), lp, 30.0)
+        sim.step(0.5)  # all velocities 0: no forces; agent 0 arrives at (10, 0) with v = (-1, 0)
+        a = sim.agents
+        assert tuple(a[0].position) == (10.0, 0.0) and tuple(a[0].velocity) == (-1.0, 0.0)
+        sim.step(0.05)
+        a = sim.agents
+        assert sim.last_report["n_tti_zero"] == 0
+        assert a[0].velocity[0] == -1.0
+        assert a[0].velocity[1] == pytest.approx(expect, rel=2e-6), cls.__name__
+        assert tuple(a[1].velocity) == (0.0, 0.0)  # the larger id has right of way: weight 0
+        # never collide: the walker on the far side, walking away
+        sim = cls(LocationHash2D(200.0, 200.0, 20.0, (-100.0, -100.0)))
+        sim.add_agents([(-9.5, 0.0)], StubHighLevelPlan((-1.0, 0.0)), lp, 30.0)
+        sim.add_agents([(0.0, 0.0)], StubHighLevelPlan((0.0, 0.0)), lp, 30.0)
+        sim.step(0.5)
+        sim.step(0.05)
+        assert tuple(sim.agents[0].velocity) == (-1.0, 0.0)
+
+
 @pytest.mark.parametrize("speed", [1e-20, 1e-35])
 def test_tiny_relative_velocities_do_not_read_as_collisions(speed):
     """|rel_vel|^2 underflows in f32 (not in the reference's f64): a flushed `a` with b != 0
@@ -413,6 +444,37 @@ class SwirlPlan(HighLevelPlanner):
         return (-0.2 * (y - 50.0) / 10.0, 0.2 * (x - 50.0) / 10.0)
 
 
+def test_source_occupancy_on_a_grid_taller_than_wide():
+    """lib.rs:212-217 on a grid with more x rows than the row stride (width 20, height 80, cell 2:
+    stride 10, 40 rows).  A slow walker standing within 0.4 of its source in row 35 must block
+    the next spawn there, as in the reference (get_bounds clamps nothing, location_hash_2d.rs:
+    103-122); an engine that clamped the row range by the stride let such sources spawn every
+    step.  Engine (tiled and gather) vs oracle: same ids, same spawn counts per step."""
+    def run(cls, flags=0):
+        kw = {"flags": flags} if cls is Simulation else {}
+        sim = cls(LocationHash2D(20.0, 80.0, 2.0, (0.0, 0.0)), **kw)
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        # filler crowd so that the tiled kernel has something to tile (and marks sources)
+        pts = scenes.jittered_lattice(2400, 0.63, (3.0, 2.0), 0.2, 5, columns=20)
+        pts = np.stack([pts[:, 1] * 0.55, pts[:, 0]], axis=1)  # x in [1, 45), y in [3, 16)
+        sim.add_agents(pts, StubHighLevelPlan((0.0, 0.0)), lp, 2.0)
+        for x, y in ((70.3, 4.0), (73.1, 7.0), (76.6, 10.0), (5.2, 17.5)):
+            sim.add_source_sink(SourceSink((x, y), 0.5, MonotonicCrowd(100.0),
+                                           StubHighLevelPlan((0.0, 0.05)), NoLocalPlan(), [(x, 19.5)], False, 2.0))
+        counts = []
+        for _ in range(60):
+            sim.step(0.05)
+            counts.append(sim.last_report["n_spawned"])
+        return sim.read_agents(), counts
+
+    a, ca = run(Simulation, 2)
+    g, cg = run(Simulation, 1)
+    b, cb = run(OracleSimulation)
+    # 0.05 m/s * 0.05 s = 2.5 mm per step: a walker leaves the 0.4 m circle after 160 steps
+    assert ca == cb == cg and sum(cb) == 4
+    assert (a["id"] == b["id"]).all() and a.tobytes() == g.tobytes()
+
+
 def test_callback_high_level_planner():
     grid = dict(width=100.0, height=100.0, cell_size=2.0, offset=(0.0, 0.0))
     pts = scenes.jittered_lattice(400, 1.0, (40.0, 40.0), 0.2, 5)
@@ -638,9 +700,11 @@ def test_route_follower_stream_matches_oracle(local, steps, flags):
            [(round(s[0], 3), round(s[1], 3), g) for s, g in rb.calls]
 
 
-def test_streaming_snapshots_match_read_agents():
-    """cs_snapshot_request / _acquire: a frame per step without waiting for it before the next
-    step is queued; every frame equals what a synchronous read of a twin simulation gives."""
+def test_streaming_snapshots_match_the_oracle():
+    """cs_snapshot_request / _acquire: a frame per step without waiting for it
+    before the next step is queued.  Every streamed frame is compared with the f64 ORACLE's
+    `agents` after the same number of steps (ids, next_waypoint exact; |dp| / L <= 1e-4; velocities
+    to 1e-4 of the walking speed), and with the engine's own synchronous read-back at the end."""
     def build(cls):
         sim = cls(LocationHash2D(120.0, 120.0, 2.0, (0.0, 0.0)))
         lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
@@ -650,7 +714,7 @@ def test_streaming_snapshots_match_read_agents():
             sim.add_source_sink(SourceSink((10.0, 10.0 + 3.0 * k), 1.0, SeededPoissonCrowd(3.0, 7 + k),
                                            StubHighLevelPlan((1.3, 0.0)), lp, [(25.0, 10.0 + 3.0 * k)], False, 2.0))
         return sim
-    fast, twin = build(Simulation), build(Simulation)
+    fast, ora = build(Simulation), build(OracleSimulation)
     assert fast.snapshot() is None
     frames = []
     for k in range(60):
@@ -658,14 +722,23 @@ def test_streaming_snapshots_match_read_agents():
         fast.request_snapshot()
         got = fast.snapshot(wait=True)
         frames.append((got[1], np.sort(got[0].copy(), order="id")))
+    worst_p = worst_v = 0.0
     for k in range(60):
-        twin.step(0.05)
-        a = twin.read_agents()
+        ora.step(0.05)
+        b = ora.read_agents()
         step, f = frames[k]
-        assert step == k + 1 and len(f) == len(a)
-        assert (f["id"] == a["id"]).all() and (f["next_waypoint"] == a["next_waypoint"]).all()
-        assert np.array_equal(f["x"], a["x"]) and np.array_equal(f["y"], a["y"])
-        assert np.array_equal(f["vx"].astype(np.float64), a["vx"]) and np.array_equal(f["vy"].astype(np.float64), a["vy"])
+        assert step == k + 1 and len(f) == len(b)
+        assert (f["id"] == b["id"]).all() and (f["next_waypoint"] == b["next_waypoint"]).all()
+        worst_p = max(worst_p, float(np.hypot(f["x"] - b["x"], f["y"] - b["y"]).max() / 120.0))
+        worst_v = max(worst_v, float(np.hypot(f["vx"] - b["vx"], f["vy"] - b["vy"]).max() / 1.3))
+    print(f"snapshots vs oracle over 60 frames: |dp|/L {worst_p:.2e}, |dv|/v {worst_v:.2e}, "
+          f"{len(frames[-1][1])} agents in the last frame")
+    assert worst_p <= 1e-4 and worst_v <= 1e-4 and len(frames[-1][1]) > 3000
+    # the streamed frame is the state read_agents returns (same bits, f32 velocities)
+    a = fast.read_agents()
+    f = frames[-1][1]
+    assert (f["id"] == a["id"]).all() and np.array_equal(f["x"], a["x"]) and np.array_equal(f["y"], a["y"])
+    assert np.array_equal(f["vx"].astype(np.float64), a["vx"]) and np.array_equal(f["vy"].astype(np.float64), a["vy"])
     # double buffering: two requests in flight, the older one stays readable until the second next request
     fast.step(0.05, report=False)
     fast.request_snapshot()
@@ -676,11 +749,9 @@ def test_streaming_snapshots_match_read_agents():
     assert fast.snapshot(wait=True)[1] == 62
     assert np.array_equal(first, keep)
     # the oracle exposes the same calls (plain copies)
-    ora = build(OracleSimulation)
-    ora.step(0.05)
     ora.request_snapshot()
     s, step = ora.snapshot()
-    assert step == 1 and len(s) == len(ora)
+    assert step == 60 and len(s) == len(ora)
 
 
 def test_three_way_parity_isolates_rounding_from_kernel_errors():

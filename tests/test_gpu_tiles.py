@@ -281,7 +281,14 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
             from test_oracle_reference_kats import MockEventListener
             listener = MockEventListener()
             tiles.add_event_listener(listener)
+        if kind == "sinks" and layout == (2, 1) and rank == 1:
+            # a listener on ONE rank only: that rank probes and commits through its host, the other
+            # keeps its flags on the device; the one shared all-reduce keeps them in step
+            from test_oracle_reference_kats import MockEventListener
+            tiles.add_event_listener(MockEventListener())
         for k in range(400):
+            if k == 120 and kind == "sinks":  # a removed sink keeps its slot: flags stay one per slot
+                tiles.remove_source_sink(3)
             tiles.step(dt, report=(k in (150, 151)))  # mostly the device-side spawn path
             if k == 200:  # a collective removal: the youngest walker, whichever rank holds it
                 ids = [None] * world
@@ -330,6 +337,8 @@ def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path, kind, layout, p
         heard = MockEventListener()
         single.add_event_listener(heard)
     for k in range(400):
+        if k == 120 and kind == "sinks":
+            single.remove_source_sink(3)
         single.step(dt, report=False)
         if k == 200:
             single.remove_agents(int(single.read_agents()["id"].max()))
@@ -399,8 +408,9 @@ def test_distributed_tiles_on_the_rccl_backend_single_rank(tmp_path):
 
 
 def test_full_size_crowd_invariants():
-    """BASELINE.json configs[1] at its full size (1M agents, 2.5 agents/m^2, eyesight 2 m, cell
-    2 m), through properties that need no oracle run: the LDS-tiled and the gather kernel give
+    """BASELINE.json configs[2]'s crowd at its full size (1M agents uniform, 2.5 agents/m^2, eyesight
+    2 m, cell 2 m; configs[1], 100k agents, is tests/test_gpu_configs_full_size.py), through
+    properties that need no oracle run: the LDS-tiled and the gather kernel give
     the same bits, a 4 x 2 tile mesh (configs[2]'s decomposition) gives the same bits as one
     engine, two runs give the same bits, nobody is lost or duplicated, every agent feels a
     finite non-zero force."""
@@ -454,12 +464,21 @@ def test_removals_on_a_tile_mesh_match_the_single_engine():
         mesh.remove_agents(victims[0])
     with pytest.raises(CrowdSimError, match="unknown agent id"):
         mesh.remove_agents(10 ** 9)
+    from test_oracle_reference_kats import MockEventListener
+    heard_s, heard_m = MockEventListener(), MockEventListener()
     for k in range(300):
+        # after a sink is gone the host-side spawn path must still size its flags by sink SLOTS
+        # (the engine keeps the slot): steps with a report, then with a listener
+        if k == 200:
+            single.add_event_listener(heard_s)
+            mesh.add_event_listener(heard_m)
         single.step(0.05, report=False)
-        mesh.step(0.05, report=False)
+        mesh.step(0.05, report=(100 <= k < 110))
     a, b = single.read_agents(), mesh.read_agents()
     assert len(a) > 100 and not set(victims) & set(a["id"].tolist())
     assert a.tobytes() == b.tobytes()
+    assert len(heard_s.added) > 20 and sorted(heard_s.added) == sorted(heard_m.added)
+    assert sorted(heard_s.removed) == sorted(heard_m.removed)
 
 
 @pytest.mark.parametrize("seed", range(24))
