@@ -1,0 +1,222 @@
+// NEVER COMPILED (no Rust toolchain in the build image).  CHECKED MECHANICALLY:
+// tools/check_ffi_layout.py parses this file and include/crowdstep.h and asserts the same
+// symbols, argument order and types, struct field order and types, constants, and (through a
+// generated static_assert translation unit compiled with g++) the sizes and field offsets that
+// #[repr(C)] gives these structs on x86-64.  Keep one item per line group as below: the checker
+// reads this file with a small parser, not with rustc.
+//
+// Every item names the reference item it replaces in include/crowdstep.h.
+
+#![allow(non_camel_case_types)]
+
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const CS_ABI_VERSION: u32 = 1;
+
+pub const CS_CFG_DEFAULT: u32 = 0;
+pub const CS_CFG_FORCE_GATHER: u32 = 1;
+pub const CS_CFG_FORCE_TILED: u32 = 2;
+pub const CS_CFG_DENSE: u32 = 4;
+
+pub const CS_HLP_NONE: u32 = 0;
+pub const CS_HLP_CONSTANT: u32 = 1;
+pub const CS_HLP_ID_PARITY: u32 = 2;
+pub const CS_HLP_CALLBACK: u32 = 3;
+pub const CS_HLP_ROUTE: u32 = 4;
+pub const CS_ROUTE_MAX_WAYPOINTS: usize = 1023;
+
+pub const CS_GEN_MONOTONIC: u32 = 0;
+pub const CS_GEN_POISSON_SEEDED: u32 = 1;
+pub const CS_GEN_CALLBACK: u32 = 2;
+
+pub const CS_EVENT_SPAWNED: u32 = 1;
+pub const CS_EVENT_DESTROYED: u32 = 2;
+
+pub const CS_K_NEIGHBOUR_FORCE: u32 = 0;
+pub const CS_K_SCAN: u32 = 1;
+pub const CS_K_SCATTER: u32 = 2;
+pub const CS_K_SPAWN: u32 = 3;
+pub const CS_K_HALO: u32 = 4;
+pub const CS_K_COUNT: u32 = 5;
+
+pub const CS_DIR_XLO: u32 = 0;
+pub const CS_DIR_XHI: u32 = 1;
+pub const CS_DIR_YLO: u32 = 2;
+pub const CS_DIR_YHI: u32 = 3;
+pub const CS_DIR_XLO_YLO: u32 = 4;
+pub const CS_DIR_XLO_YHI: u32 = 5;
+pub const CS_DIR_XHI_YLO: u32 = 6;
+pub const CS_DIR_XHI_YHI: u32 = 7;
+pub const CS_HALO_RECORD_BYTES: u32 = 40;
+
+/// Opaque engine handle (`struct cs_engine`).
+#[repr(C)]
+pub struct cs_engine {
+    _private: [u8; 0],
+}
+
+/// LocationHash2D::new(width, height, cell_size, offset), location_hash_2d.rs:33-51
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_grid_desc {
+    pub width: f64,
+    pub height: f64,
+    pub cell_size: f64,
+    pub offset_x: f64,
+    pub offset_y: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_device_cfg {
+    pub device_ordinal: i32,
+    pub flags: u32,
+    pub tile_cx0: u32,
+    pub tile_cx1: u32,
+    pub tile_cy0: u32,
+    pub tile_cy1: u32,
+    pub halo_cells: u32,
+    pub reserved: u32,
+    pub capacity_hint: u64,
+    pub stream: *mut c_void,
+}
+
+/// Zanlungo::new(..), zanlungo.rs:31-48
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_zanlungo_params {
+    pub agent_scale: f64,
+    pub obstacle_scale: f64,
+    pub reaction_time: f64,
+    pub force_distance: f64,
+    pub agent_mass: f64,
+    pub agent_radius: f64,
+}
+
+pub type cs_hlp_velocity_fn = Option<unsafe extern "C" fn(user: *mut c_void, n: usize, ids: *const u64, pos_xy: *const f64, vel_xy: *const f64, time_s: f64, out_vel_xy: *mut f64, out_some: *mut u8)>;
+pub type cs_hlp_set_target_fn = Option<unsafe extern "C" fn(user: *mut c_void, id: u64, pos_x: f64, pos_y: f64, point_x: f64, point_y: f64, tol_x: f64, tol_y: f64)>;
+pub type cs_hlp_remove_fn = Option<unsafe extern "C" fn(user: *mut c_void, id: u64)>;
+pub type cs_route_plan_fn = Option<unsafe extern "C" fn(user: *mut c_void, start_x: f64, start_y: f64, goal_x: f64, goal_y: f64, out_xy: *mut f64, cap: usize) -> usize>;
+pub type cs_generator_fn = Option<unsafe extern "C" fn(user: *mut c_void, dt_seconds: f64) -> usize>;
+
+/// HighLevelPlanner as data, highlevel_planners.rs:8-16
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cs_hlp_desc {
+    pub kind: u32,
+    pub vx: f64,
+    pub vy: f64,
+    pub velocity: cs_hlp_velocity_fn,
+    pub set_target: cs_hlp_set_target_fn,
+    pub remove_agent: cs_hlp_remove_fn,
+    pub user: *mut c_void,
+    pub route_plan: cs_route_plan_fn,
+    pub route_scale: f64,
+    pub route_arrive: f64,
+    pub route_speed: f64,
+}
+
+/// struct SourceSink, source_sink.rs:36-60
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cs_source_sink_desc {
+    pub source_x: f64,
+    pub source_y: f64,
+    pub radius_sink: f64,
+    pub generator_kind: u32,
+    pub rate: f64,
+    pub seed: u64,
+    pub generator: cs_generator_fn,
+    pub generator_user: *mut c_void,
+    pub hlp: u32,
+    pub lp: u32,
+    pub waypoints_xy: *const f64,
+    pub n_waypoints: usize,
+    pub loop_forever: i32,
+    pub agent_eyesight_range: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct cs_step_report {
+    pub n_agents: u64,
+    pub n_spawned: u64,
+    pub n_destroyed: u64,
+    pub n_waypoint_hits: u64,
+    pub n_tti_zero: u64,
+    pub n_nonfinite: u64,
+    pub n_clamped: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_event {
+    pub kind: u32,
+    pub source_sink: u32,
+    pub id: u64,
+    pub x: f64,
+    pub y: f64,
+}
+
+/// pub struct Agent, lib.rs:46-65
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_agent_view {
+    pub id: u64,
+    pub x: f64,
+    pub y: f64,
+    pub vx: f64,
+    pub vy: f64,
+    pub next_waypoint: u64,
+    pub eyesight_range: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_snapshot_record {
+    pub x: f64,
+    pub y: f64,
+    pub vx: f32,
+    pub vy: f32,
+    pub id: u32,
+    pub next_waypoint: u32,
+}
+
+extern "C" {
+    pub fn cs_abi_version() -> u32;
+    pub fn cs_create(grid: *const cs_grid_desc, cfg: *const cs_device_cfg) -> *mut cs_engine;
+    pub fn cs_destroy(e: *mut cs_engine);
+    pub fn cs_last_error(e: *const cs_engine) -> *const c_char;
+    pub fn cs_backend_name(e: *const cs_engine) -> *const c_char;
+    pub fn cs_register_zanlungo(e: *mut cs_engine, p: *const cs_zanlungo_params) -> u32;
+    pub fn cs_register_no_local_plan(e: *mut cs_engine) -> u32;
+    pub fn cs_register_hlp(e: *mut cs_engine, d: *const cs_hlp_desc) -> u32;
+    pub fn cs_add_agents(e: *mut cs_engine, xy: *const f64, n: usize, hlp: u32, lp: u32, eyesight: f64, out_ids: *mut u64) -> c_int;
+    pub fn cs_remove_agent(e: *mut cs_engine, id: u64) -> c_int;
+    pub fn cs_add_source_sink(e: *mut cs_engine, d: *const cs_source_sink_desc) -> u32;
+    pub fn cs_remove_source_sink(e: *mut cs_engine, handle: u32);
+    pub fn cs_source_sink_slots(e: *mut cs_engine) -> usize;
+    pub fn cs_step(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
+    pub fn cs_synchronize(e: *mut cs_engine) -> c_int;
+    pub fn cs_agent_count(e: *mut cs_engine) -> usize;
+    pub fn cs_read_agents(e: *mut cs_engine, out: *mut cs_agent_view, cap: usize) -> usize;
+    pub fn cs_drain_events(e: *mut cs_engine, out: *mut cs_event, cap: usize) -> usize;
+    pub fn cs_event_recording(e: *mut cs_engine, on: c_int);
+    pub fn cs_snapshot_request(e: *mut cs_engine) -> c_int;
+    pub fn cs_snapshot_acquire(e: *mut cs_engine, wait: c_int, out: *mut *const cs_snapshot_record, n: *mut usize, step_index: *mut u64) -> c_int;
+    pub fn cs_query_radius(e: *mut cs_engine, radius: f64, x: f64, y: f64, out_ids: *mut u64, cap: usize) -> usize;
+    pub fn cs_query_knn(e: *mut cs_engine, k: usize, x: f64, y: f64, out_ids: *mut u64) -> usize;
+    pub fn cs_profile_enable(e: *mut cs_engine, kernel_mask: u32);
+    pub fn cs_profile_stride(e: *mut cs_engine, every: u32);
+    pub fn cs_profile_read(e: *mut cs_engine, kernel: u32, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn cs_profile_reset(e: *mut cs_engine);
+    pub fn cs_halo_set_buffers(e: *mut cs_engine, dir: u32, send_dev: *mut c_void, recv_dev: *mut c_void, capacity_records: u64) -> c_int;
+    pub fn cs_halo_pack(e: *mut cs_engine, axis: u32) -> c_int;
+    pub fn cs_halo_unpack(e: *mut cs_engine, axis: u32) -> c_int;
+    pub fn cs_halo_pack_all(e: *mut cs_engine) -> c_int;
+    pub fn cs_halo_unpack_all(e: *mut cs_engine) -> c_int;
+    pub fn cs_spawn_probe(e: *mut cs_engine, dt_seconds: f64, flags: *mut u8, cap: usize) -> usize;
+    pub fn cs_spawn_commit(e: *mut cs_engine, flags: *const u8, n: usize) -> c_int;
+    pub fn cs_spawn_probe_dev(e: *mut cs_engine, dt_seconds: f64, flags_dev: *mut c_int, cap: usize) -> c_int;
+    pub fn cs_spawn_commit_dev(e: *mut cs_engine, flags_dev: *const c_int, n: usize) -> c_int;
+}

@@ -20,15 +20,21 @@ from rmf_crowdsim_amd.tiles import LocalTileMesh
 pytestmark = pytest.mark.gpu
 
 
-def _rel(a, b, scale):
+def _rel(a, b, scale, ok=None):
     assert (a["id"] == b["id"]).all()
-    return float(np.hypot(a["x"] - b["x"], a["y"] - b["y"]).max() / scale)
+    dp = np.hypot(a["x"] - b["x"], a["y"] - b["y"])
+    return float((dp if ok is None else dp[ok]).max() / scale)
 
 
 def test_config1_exact_size():
     """configs[1] as written: 100,000 agents uniform on 200 x 200 m (2.5 / m^2), Zanlungo, cell 2 m,
     eyesight 2 m, dt 0.05 s, one MI355X.  Engine vs f64 oracle over 8 steps (every step compared),
-    then the three-way split: engine (cell-relative f32) / oracle built in f32 / f64 oracle."""
+    then the three-way split: engine (cell-relative f32) / oracle built in f32 / f64 oracle.
+
+    The reference's f64 path has an underflow flaw of its own: a pair whose relative
+    velocity is ~1e-162 reads as "colliding now" (t_i = 0) and the larger id goes NaN; it strikes 5
+    of these 100,000 agents in steps 3-4.  f32 flushes such forces to exactly 0, so the engine
+    cannot hit it: it must stay finite with n_tti_zero = 0, and those agents are left out."""
     n = 100_000
     pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0)
     assert abs(extent - 200.0) < 1.0  # 317 x 317 lattice sites, 0.632 m apart
@@ -42,17 +48,19 @@ def test_config1_exact_size():
         for s in sims.values():
             s.step(0.05)
         a, b = sims["gpu"].read_agents(), sims["o64"].read_agents()
-        assert len(a) == n
-        worst = max(worst, _rel(a, b, extent))
-        assert sims["gpu"].last_report["n_tti_zero"] == sims["o64"].last_report["n_tti_zero"] == 0
-        assert sims["gpu"].last_report["n_nonfinite"] == 0
+        assert len(a) == n and np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
+        ok = np.isfinite(b["x"])
+        assert (~ok).sum() <= n // 2000
+        worst = max(worst, _rel(a, b, extent, ok))
+        assert sims["gpu"].last_report["n_tti_zero"] == 0 and sims["gpu"].last_report["n_nonfinite"] == 0
     c = sims["o32"].read_agents()
-    e_gpu_64, e_32_64, e_gpu_32 = _rel(a, b, extent), _rel(c, b, extent), _rel(a, c, extent)
-    force = np.hypot(b["vx"], np.abs(b["vy"]) - scenes.CREEP_SPEED)
-    dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])
+    ok = ok & np.isfinite(c["x"])
+    e_gpu_64, e_32_64, e_gpu_32 = _rel(a, b, extent, ok), _rel(c, b, extent, ok), _rel(a, c, extent, ok)
+    force = np.hypot(b["vx"], np.abs(b["vy"]) - scenes.CREEP_SPEED)[ok]
+    dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])[ok]
     print(f"configs[1] 100k: worst |dp|/L over 8 steps {worst:.2e}; gpu-f64 {e_gpu_64:.2e}, f32-f64 {e_32_64:.2e}, "
           f"gpu-f32 {e_gpu_32:.2e}; forced {float(np.mean(force > 0)):.3f}; |dv| p99.9/max|F| "
-          f"{float(np.quantile(dv, 0.999) / force.max()):.2e}")
+          f"{float(np.quantile(dv, 0.999) / force.max()):.2e}; reference-path NaN agents {int((~ok).sum())}")
     assert worst <= 1e-4 and np.mean(force > 0) > 0.95
     assert np.quantile(dv, 0.999) <= 2e-3 * force.max()
     # the engine's cell-relative f32 must not be further from the f64 path than plain f32 is
@@ -84,7 +92,7 @@ def test_config3_one_million_agents_sustained_by_source_sinks():
         else:
             t = Simulation(LocationHash2D(**grid), flags=2 if name == "tiled" else 1, capacity_hint=1_200_000)
         _stream(t, lanes, lp, 2.0)
-        spawned = destroyed = 0
+        spawned = destroyed = late_spawned = late_destroyed = 0
         for k in range(steps):
             # the two engines report every step (host path: counts add up exactly); the mesh runs
             # fire-and-forget (spawn flags and ids stay on the device)
@@ -92,14 +100,17 @@ def test_config3_one_million_agents_sustained_by_source_sinks():
             if name != "mesh":
                 spawned += t.last_report["n_spawned"]
                 destroyed += t.last_report["n_destroyed"]
-        runs[name] = (t.read_agents(), spawned, destroyed, t)
-    a, spawned, destroyed, sim = runs["tiled"]
-    g, g_spawned, g_destroyed, _ = runs["gather"]
+                if k >= steps - 28:  # the lanes release in lock-step, every 7th step (0.4 m at 1.3 m/s)
+                    late_spawned += t.last_report["n_spawned"]
+                    late_destroyed += t.last_report["n_destroyed"]
+        runs[name] = (t.read_agents(), spawned, destroyed, t, late_spawned, late_destroyed)
+    a, spawned, destroyed, sim, late_spawned, late_destroyed = runs["tiled"]
+    g, g_spawned, g_destroyed = runs["gather"][:3]
     m = runs["mesh"][0]
     print(f"configs[3]: {len(a)} agents alive after {steps} steps, {spawned} spawned, {destroyed} destroyed, "
-          f"last step +{sim.last_report['n_spawned']} -{sim.last_report['n_destroyed']}")
+          f"last 28 steps +{late_spawned} -{late_destroyed}")
     assert 800_000 < len(a) <= 1_050_000
-    assert sim.last_report["n_spawned"] > 1000 and sim.last_report["n_destroyed"] > 1000  # steady state
+    assert late_spawned >= 75_000 and late_destroyed >= 75_000  # steady state: births balance deaths
     assert len(np.unique(a["id"])) == len(a)
     assert a["id"].max() < spawned + 1 and spawned - destroyed == len(a)
     assert (spawned, destroyed) == (g_spawned, g_destroyed)
