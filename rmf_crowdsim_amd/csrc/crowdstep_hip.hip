@@ -146,6 +146,14 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   e->gdev.own_y1 = oy1;
   e->gdev.org_x = org_x;
   e->gdev.org_y = org_y;
+  {  // fixed-point unit of the neighbour pass (fix_rel): the cell size is at most 2^25 units, i.e.
+     // 2^-24 m for cells of (1, 2] m: the f32 spacing of an offset of half a cell, or finer
+    int bits = 25 - (int)std::ceil(std::log2(std::max(grid->cell_size, 1e-30)));
+    bits = std::max(-60, std::min(bits, 60));
+    e->gdev.fix_scale = (float)std::ldexp(1.0, bits);
+    e->gdev.fix_inv = (float)std::ldexp(1.0, -bits);
+    e->gdev.cs_fix = (int32_t)std::llrint(grid->cell_size * std::ldexp(1.0, bits));
+  }
   if (cfg && cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
@@ -156,18 +164,13 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, e->device);
   e->backend = std::string("hip:") + prop.gcnArchName;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<false>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-    (void)hipGetLastError();  // not fatal: the default 64 KiB covers eyesight <= 2 cells
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-    (void)hipGetLastError();  // (wide cells: a large staged tile)
+    (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
   {  // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB
     hipFuncAttributes fa;
     size_t st = 0;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled<true>)) == hipSuccess)
-      st = std::max(st, (size_t)fa.sharedSizeBytes);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled<false>)) == hipSuccess)
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled)) == hipSuccess)
       st = std::max(st, (size_t)fa.sharedSizeBytes);
     (void)hipGetLastError();
     if (st) e->tile_static_lds = (uint32_t)st;
