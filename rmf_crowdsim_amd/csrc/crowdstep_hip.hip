@@ -146,9 +146,10 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   e->gdev.own_y1 = oy1;
   e->gdev.org_x = org_x;
   e->gdev.org_y = org_y;
-  {  // fixed-point unit of the neighbour pass (fix_rel): the cell size is at most 2^25 units, i.e.
-     // 2^-24 m for cells of (1, 2] m: the f32 spacing of an offset of half a cell, or finer
-    int bits = 25 - (int)std::ceil(std::log2(std::max(grid->cell_size, 1e-30)));
+  {  // fixed-point unit of the neighbour pass (fix_rel): the cell size is at most 2^23 units, i.e.
+     // 2^-22 m for cells of (1, 2] m (two f32 spacings of an offset in the upper half of the
+     // cell), so that a window of up to ~120 columns fits 2^30 units (tile_max_cols)
+    int bits = 23 - (int)std::ceil(std::log2(std::max(grid->cell_size, 1e-30)));
     bits = std::max(-60, std::min(bits, 60));
     e->gdev.fix_scale = (float)std::ldexp(1.0, bits);
     e->gdev.fix_inv = (float)std::ldexp(1.0, -bits);
@@ -182,7 +183,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
-  if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(TILE_THREADS, std::max(32, atoi(v)));
+  if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
   bool ok = true;
   ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
@@ -513,14 +514,14 @@ size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_id
 
 #ifdef CS_PHASE_CLOCKS
 // profiling build only: read (and optionally clear) the per-phase wave cycles of the tiled kernel
-void cs_debug_phase_cycles(cs_engine* e, unsigned long long* out8, int reset) {
+void cs_debug_phase_cycles(cs_engine* e, unsigned long long* out, int reset) {
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
-  static unsigned long long host[PHASE_SLOTS][8];
+  static unsigned long long host[PHASE_SLOTS][PHASE_COUNT];
   hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof host);
-  for (int k = 0; k < 8; ++k) {
-    out8[k] = 0;
-    for (int q = 0; q < PHASE_SLOTS; ++q) out8[k] += host[q][k];
+  for (int k = 0; k < PHASE_COUNT; ++k) {
+    out[k] = 0;
+    for (int q = 0; q < PHASE_SLOTS; ++q) out[k] += host[q][k];
   }
   if (reset) {
     memset(host, 0, sizeof host);

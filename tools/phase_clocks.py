@@ -39,13 +39,14 @@ try:
     fn = lib.cs_debug_phase_cycles
     fn.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     fn.restype = None
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 12)()
     fn(sim._engine, out, 1)
     for _ in range(args.steps):
         sim.step(0.05, report=False)
     fn(sim._engine, out, 1)
-    names = ["geometry", "staging", "agent setup", "filter", "time-to-collision", "forces", "epilogue"]
-    total = float(sum(out[:7])) or 1.0
+    names = ["descriptor", "geometry", "staging: loads", "staging: barrier 1", "staging: placement",
+             "staging: barrier 2", "agent setup", "filter", "time-to-collision", "forces", "epilogue"]
+    total = float(sum(out[:11])) or 1.0
     print(f"agents {args.agents} eyesight {args.eyesight} cell {args.cell}: wave cycles per step {total / args.steps:.4g}")
     for n, v in zip(names, out):
         print(f"  {n:18s} {100.0 * v / total:5.1f} %   {v / args.steps / (args.agents / 64.0):8.0f} cycles per wave of 64 agents")
