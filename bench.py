@@ -23,31 +23,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# Algorithmic HBM bytes of the neighbour kernel per agent per launch (DESIGN.md "K4"):
-# read own record off 8 + vel 8 + id 4 + cell 4 + meta 4 = 28 and the cell table 4 B/cell
-# amortised (counted per agent below); write off 8 + vel 8 + id 4 + meta 4 + cell 4 + rank 4 = 32.
-K4_READ_BYTES = 28
-K4_WRITE_BYTES = 32
+# Algorithmic HBM bytes of the neighbour kernel per launch, as SURVEY.md section 8(d) counts them: read
+# 32 B/agent (pos 8 + vel 8 + own pref 8 + id 4 + eyesight/group 4) + 8 B per cell (start, count);
+# write 16 B/agent (new pos 8 + new vel 8).  (What the fused kernel really moves, without
+# neighbour re-reads, is 60 B/agent + 4 B/cell: it also carries id / meta / cell / rank through
+# for the re-sort; `roofline.fused_kernel_bytes_per_launch` reports that figure.)
+K4_READ_BYTES = 32
+K4_WRITE_BYTES = 16
+K4_CELL_BYTES = 8
+K4_FUSED_BYTES_PER_AGENT, K4_FUSED_BYTES_PER_CELL = 60, 4
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave64 VALU instructions per second: 1024 SIMDs, one per 2 clocks
 
 
-def build_crowd(sim_cls, n, cell, eyesight, speed, device=0, stream=None, capacity=0):
+def profile_key(workload_desc):
+    """Identifies what a cached PMC summary (profiles/rNN/k4_traffic.json) was measured on: the
+    kernel sources, the compiler flags and the workload.  A summary with another key is stale."""
+    import hashlib
+    from rmf_crowdsim_amd import _native
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(_native.CSRC)):
+        with open(os.path.join(_native.CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    h.update(" ".join(_native.HIPCC_FLAGS).encode())
+    h.update(workload_desc.encode())
+    return h.hexdigest()[:16]
+
+
+def walk_room(steps):
+    """Free metres on the high-x side for a crowd that walks +x at 1.3 m/s for `steps` steps."""
+    from rmf_crowdsim_amd import scenes
+    return scenes.WALK_SPEED * 0.05 * (steps + 8) + 4.0
+
+
+def populate(target, workload, pts, group, speed, lp, eyesight):
+    from rmf_crowdsim_amd import scenes
+    if workload == "walk":
+        scenes.add_walking_crowd(target, pts, group, lp, eyesight, creep=speed)
+    else:
+        scenes.add_counterflow(target, pts, group, speed, lp, eyesight)
+
+
+def build_crowd(sim_cls, n, cell, eyesight, speed, workload="walk", steps=200, device=0, stream=None, capacity=0):
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo, scenes
-    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell)
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell,
+                                                    room=walk_room(steps) if workload == "walk" else 0.0)
     kwargs = {}
     if sim_cls.__name__ == "Simulation":
         kwargs = dict(device=device, stream=stream, capacity_hint=capacity)
     sim = sim_cls(LocationHash2D(**grid), **kwargs)
-    scenes.add_counterflow(sim, pts, group, speed, Zanlungo(*scenes.METRIC_ZANLUNGO), eyesight)
+    populate(sim, workload, pts, group, speed, Zanlungo(*scenes.METRIC_ZANLUNGO), eyesight)
     return sim, grid, extent
 
 
-def cpu_baseline(agents, cell, eyesight, speed, budget_s=15.0):
+def cpu_baseline(agents, cell, eyesight, speed, workload="walk", budget_s=15.0):
     """Times the CPU oracle (the reference-shaped single-thread port) on a bounded sample of the
     same workload: same density / parameters, fewer agents, a few steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_sim import OracleSimulation
     n = min(agents, 100_000)
-    sim, _, _ = build_crowd(OracleSimulation, n, cell, eyesight, speed)
+    sim, _, _ = build_crowd(OracleSimulation, n, cell, eyesight, speed, workload=workload, steps=110)
     sim.step(0.05)  # first step: all velocities 0 -> no forces; not representative
     steps, t0 = 0, time.perf_counter()
     while True:
@@ -63,7 +97,7 @@ def cpu_baseline(agents, cell, eyesight, speed, budget_s=15.0):
     }
 
 
-def cpu_baseline_openmp(agents, cell, eyesight, speed, budget_s=8.0):
+def cpu_baseline_openmp(agents, cell, eyesight, speed, workload="walk", budget_s=8.0):
     """What a good CPU does with the same arithmetic (not the reference's shape): the oracle's
     Zanlungo on cell-sorted arrays, the agent loop spread over the host cores with OpenMP
     (oracle_fast_steps; bit-identical to the oracle, tests/test_oracle_reference_kats.py)."""
@@ -73,9 +107,12 @@ def cpu_baseline_openmp(agents, cell, eyesight, speed, budget_s=8.0):
     from rmf_crowdsim_amd import scenes
     n = min(agents, 1_000_000)
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share
-    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell)
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=cell,
+                                                    room=walk_room(60) if workload == "walk" else 0.0)
     pref = np.zeros((n, 2))
     pref[:, 1] = np.where(group == 0, speed, -speed)
+    if workload == "walk":
+        pref[:, 0] = scenes.WALK_SPEED
     xy, vel, _ = fast_steps(pts, pref, scenes.METRIC_ZANLUNGO, eyesight, grid, 0.05, 1, threads=threads)
     xy, vel, probe = fast_steps(xy, pref, scenes.METRIC_ZANLUNGO, eyesight, grid, 0.05, 1, threads=threads, vel=vel)
     steps = int(max(1, min(50, budget_s / max(probe, 1e-3))))
@@ -92,13 +129,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--agents", type=int, default=1_000_000, help="agents per GPU")
+    ap.add_argument("--agents", type=int, default=1_000_000,
+                    help="agents per GPU (weak scaling) or in all (--scaling strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank adds --agents agents to one crowd; strong: --agents agents in all, "
+                         "cut into one tile per rank (BASELINE.json configs[2]: 1M agents, 4 x 2 tiles on 8 GPUs)")
     ap.add_argument("--eyesight", type=float, default=2.0)
     ap.add_argument("--cell", type=float, default=2.0)
     ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
     ap.add_argument("--kernel", choices=["auto", "tiled", "gather"], default="auto")
-    ap.add_argument("--workload", choices=["uniform", "stream", "hotspots", "random"], default="uniform",
-                    help="uniform: BASELINE configs[1..2]; stream: configs[3], agents fed by source-sinks")
+    ap.add_argument("--workload", choices=["walk", "creep", "uniform", "stream", "hotspots", "random"], default="walk",
+                    help="walk (default): the uniform crowd of BASELINE configs[1..2] walking at 1.3 m/s with the "
+                         "creeping counter-flow on top (agents change cells at the real rate); creep (= uniform): "
+                         "the same crowd standing but for the counter-flow (non-zero forces); stream: configs[3], "
+                         "agents fed by source-sinks; hotspots: configs[4]; random: a thinned lattice")
+    ap.add_argument("--no-creep-leg", action="store_true",
+                    help="skip the short run of the creep scene whose kernel time is reported beside the default one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
     ap.add_argument("--planner", choices=["stub", "route"], default="stub",
@@ -113,11 +159,15 @@ def main():
     import torch.distributed as dist
     from rmf_crowdsim_amd import Simulation, scenes, _abi
 
+    if args.workload == "uniform":
+        args.workload = "creep"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    per_gpu = args.agents if args.scaling == "weak" else max(1, args.agents // world)
+    n_total = per_gpu * world
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
     backend = os.environ.get("CS_BENCH_BACKEND", "nccl")  # "gloo": ranks sharing one GPU (tests)
@@ -145,27 +195,29 @@ def main():
     lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
     n_sinks = 0
     tile_report = {}
+    uniform_kind = args.workload in ("walk", "creep")
+    crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload)
+    total_steps = args.steps + args.warmup + 2
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
         from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
         # longer lanes on more GPUs keep the number of sinks (one planner group each) under 65535
-        lane_length = 16.0 * max(1, (world + 1) // 2)
-        lanes, grid, fill_steps = scenes.stream_lanes(args.agents * world, lane_length=lane_length,
-                                                      cell_size=args.cell)
+        lane_length = 16.0 * max(1, (world + 1) // 2) if args.scaling == "weak" else 16.0
+        lanes, grid, fill_steps = scenes.stream_lanes(n_total, lane_length=lane_length, cell_size=args.cell)
         extent = grid["width"]
         if world == 1:
             tiling = (1, 1)
             sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
                              stream=torch.cuda.current_stream().cuda_stream,
-                             capacity_hint=int(args.agents * 1.2) + 4096)
+                             capacity_hint=int(per_gpu * 1.2) + 4096)
             stepper = sim
         else:
             tiling = default_tiling(world)
             halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
             stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
                                        density_per_cell=1.5 * scenes.METRIC_DENSITY * args.cell ** 2,
-                                       capacity_hint=int(args.agents * 1.3) + 4096, flags=flags)
+                                       capacity_hint=int(per_gpu * 1.3) + 4096, flags=flags)
             sim = stepper.sim
         plans = {}
         if args.planner == "route":
@@ -179,34 +231,34 @@ def main():
         for _ in range(fill_steps):
             stepper.step(0.05, report=False)
         speed = scenes.WALK_SPEED
-    elif world == 1:
-        tiling = (1, 1)
-        crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
-        pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
-        sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
-                         stream=torch.cuda.current_stream().cuda_stream,
-                         capacity_hint=args.agents + 1024)
-        stepper = sim
     else:
-        # weak scaling: one crowd of world * agents, cut into spatial tiles, one tile per rank;
-        # every rank sees the global add_agents call and keeps the agents of its own cells
-        tiling = default_tiling(world)
-        crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
-        pts, grid, extent, group = crowd(args.agents * world, seed=7, cell_size=args.cell)
-        halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
-        # a clustered crowd gets cuts at the quantiles of its row / column histograms
-        hot = args.workload == "hotspots"
-        stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
-                                   density_per_cell=(3.0 if hot else 1.5) * scenes.METRIC_DENSITY * args.cell ** 2,
-                                   capacity_hint=int(args.agents * (1.5 if hot else 1.1)) + 4096, flags=flags,
-                                   weights=pts if hot else None)
-        sim = stepper.sim
-        if hot:
+        if uniform_kind:
+            pts, grid, extent, group = scenes.uniform_crowd(
+                n_total, seed=7, cell_size=args.cell, room=walk_room(total_steps) if args.workload == "walk" else 0.0)
+        else:
+            pts, grid, extent, group = crowd(n_total, seed=7, cell_size=args.cell)
+        if world == 1:
+            tiling = (1, 1)
+            sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
+                             stream=torch.cuda.current_stream().cuda_stream, capacity_hint=per_gpu + 1024)
+            stepper = sim
+        else:
+            # one crowd of n_total agents, cut into spatial tiles, one tile per rank; every rank sees
+            # the global add_agents call and keeps the agents of its own cells
+            tiling = default_tiling(world)
+            halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
+            hot = args.workload == "hotspots"
+            # a clustered crowd gets cuts at the quantiles of its row / column histograms; so does the
+            # walking crowd, which stands at the low-x end of its grid
+            stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
+                                       density_per_cell=(3.0 if hot else 1.5) * scenes.METRIC_DENSITY * args.cell ** 2,
+                                       capacity_hint=int(per_gpu * (1.5 if hot else 1.15)) + 4096, flags=flags,
+                                       weights=pts if (hot or args.workload == "walk") else None)
+            sim = stepper.sim
             counts = stepper.layout.tile_counts(pts, LocationHash2D(**grid))
             tile_report = {"agents_per_tile": counts.reshape(-1).tolist(),
                            "imbalance_max_over_mean": float(counts.max() / counts.mean())}
-    if args.workload in ("uniform", "hotspots", "random"):
-        scenes.add_counterflow(stepper, pts, group, speed, lp, args.eyesight)
+        populate(stepper, args.workload, pts, group, speed, lp, args.eyesight)
         del pts, group
 
     def sync_all():
@@ -246,37 +298,94 @@ def main():
 
     # the scene must still be the scene: everyone alive and finite
     if args.debug:
-        rep = {"n_tti_zero": -1, "n_nonfinite": -1, "n_agents": args.agents}
+        rep = {"n_tti_zero": -1, "n_nonfinite": -1, "n_agents": per_gpu}
     else:
         stepper.step(0.05, report=True)
         rep = sim.last_report
-    total_agents = args.agents * world
+    total_agents = n_total
+    t_n = torch.tensor([rep["n_agents"], rep["n_tti_zero"], rep["n_nonfinite"]], dtype=torch.int64,
+                       device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t_n)
+    alive_all = int(t_n[0].item())
     if args.workload == "stream":
-        t_n = torch.tensor([rep["n_agents"]], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(t_n)
-        total_agents = int(t_n.item())  # what the sinks actually sustain, over all tiles
+        total_agents = alive_all  # what the sinks actually sustain, over all tiles
+    elif not args.debug and alive_all != n_total:
+        raise SystemExit(f"bench: {alive_all} of {n_total} agents alive after the run")
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
     ncells = int(round(grid["width"] / grid["cell_size"])) ** 2 // world  # per tile
-    alg_bytes = args.agents * (K4_READ_BYTES + K4_WRITE_BYTES) + 4 * ncells
+    agents_here = rep["n_agents"] if args.workload == "stream" else per_gpu
+    alg_bytes = agents_here * (K4_READ_BYTES + K4_WRITE_BYTES) + K4_CELL_BYTES * ncells
+    fused_bytes = agents_here * K4_FUSED_BYTES_PER_AGENT + K4_FUSED_BYTES_PER_CELL * ncells
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
 
-    # HBM traffic of the kernel from the PMC counters (separate rocprofv3 passes, FETCH_SIZE x2 on
-    # gfx950): measured offline for the default workload and kept under profiles/
-    traffic = None
-    valu_insts = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "k4_traffic.json")) as f:
-            tr = json.load(f)
-        if (tr["agents"], tr["cell"], tr["eyesight"]) == (args.agents, args.cell, args.eyesight) \
-                and args.kernel != "gather" and not args.debug and args.workload == "uniform" and world == 1:
-            traffic = tr["traffic_bytes_per_launch"]
-            valu_insts = tr.get("valu_wave_insts_per_launch")
-    except (OSError, KeyError, ValueError):
-        pass
+    desc = {
+        "walk": (f"{per_gpu} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered lattice, everyone walking +x at "
+                 f"{scenes.WALK_SPEED} m/s (6.5 cm per step: ~3 % change cell every step) with a counter-flow of "
+                 f"+-{speed} m/s in y on top, Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight {args.eyesight} m, "
+                 f"LocationHash2D cell {args.cell} m, dt 0.05 s"),
+        "creep": (f"{per_gpu} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered lattice, counter-flow {speed} m/s, "
+                  f"Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, "
+                  f"dt 0.05 s"),
+        "hotspots": (f"{per_gpu} agents/GPU, half uniform background, half in Gaussian hotspots (sigma 5 m, 800 agents "
+                     f"each), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight {args.eyesight} m, cell "
+                     f"{args.cell} m, dt 0.05 s"),
+        "random": (f"{per_gpu} agents/GPU, {scenes.METRIC_DENSITY}/m^2 on a randomly thinned 0.45 m lattice (neighbour "
+                   f"counts scatter like a real crowd's), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
+                   f"eyesight {args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
+        "stream": (f"~{per_gpu} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m apart, "
+                   f"alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight {args.eyesight} m, cell "
+                   f"{args.cell} m, dt 0.05 s"),
+    }[args.workload]
+
+    # HBM traffic and instruction counts of the kernel from the PMC counters (separate rocprofv3
+    # passes, FETCH_SIZE x2 on gfx950; tools/rocprof_passes.sh) are measured offline and cached under
+    # profiles/.  The cache is keyed by the kernel sources, the compiler flags and the workload: a
+    # summary taken on anything else is stale and reads as null here.
+    key = profile_key(f"{args.workload} agents {per_gpu} cell {args.cell} eyesight {args.eyesight} kernel {args.kernel} "
+                      f"world {world}")
+    traffic = valu_insts = None
+    pmc_source = None
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "k4_traffic.json")) as f:
+                tr = json.load(f)
+            if tr.get("profile_key") == key and not args.debug:
+                traffic, valu_insts = tr["traffic_bytes_per_launch"], tr.get("valu_wave_insts_per_launch")
+                pmc_source = f"profiles/{rnd}/k4_traffic.json"
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+
+    # the creep scene's kernel time beside the default one (same crowd, standing, non-zero forces)
+    creep_leg = None
+    if rank == 0 and world == 1 and args.workload == "walk" and not args.no_creep_leg and not args.debug:
+        del stepper, sim
+        c_sim, _, _ = build_crowd(Simulation, per_gpu, args.cell, args.eyesight, speed, workload="creep",
+                                  device=device, stream=torch.cuda.current_stream().cuda_stream, capacity=per_gpu + 1024)
+        for _ in range(10):
+            c_sim.step(0.05, report=False)
+        c_sim.synchronize()
+        c_sim.profile_reset()
+        c_sim.profile_stride(2)
+        c_sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(40):
+            c_sim.step(0.05, report=False)
+        torch.cuda.synchronize()
+        c_el = time.perf_counter() - c0
+        c_sim.profile_enable(0)
+        cp = c_sim.profile_read()["neighbour_force"]
+        c_sim.step(0.05, report=True)
+        creep_leg = {"workload": "creep", "kernel_ms": cp["total_ms"] / max(cp["launches"], 1), "ms_per_step": c_el / 40 * 1e3,
+                     "value": per_gpu * 40 / c_el, "steps": 40, "n_tti_zero": c_sim.last_report["n_tti_zero"],
+                     "n_nonfinite": c_sim.last_report["n_nonfinite"]}
+        del c_sim
 
     if rank == 0:
+        valu_frac = (valu_insts / (k4_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and k4_ms > 0) else None
         out = {
             "metric": "agent-steps/sec at 1M agents, dt=0.05 s; % HBM roofline on Zanlungo kernel",
             "value": total_agents * args.steps / elapsed,
@@ -286,57 +395,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.agents} agents/GPU uniform {scenes.METRIC_DENSITY}/m^2 jittered "
-                             f"lattice, counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
-                             f"eyesight {args.eyesight} m, LocationHash2D cell {args.cell} m, dt 0.05 s")
-                if args.workload == "uniform" else
-                (f"{args.agents} agents/GPU, half uniform background, half in Gaussian hotspots (sigma 5 m, "
-                 f"800 agents each), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
-                 f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s")
-                if args.workload == "hotspots" else
-                (f"{args.agents} agents/GPU, {scenes.METRIC_DENSITY}/m^2 on a randomly thinned 0.45 m lattice (neighbour "
-                 f"counts scatter like a real crowd's), counter-flow {speed} m/s, Zanlungo(A=1,D=0.4,m=2,R=0.2), "
-                 f"eyesight {args.eyesight} m, cell {args.cell} m, dt 0.05 s")
-                if args.workload == "random" else
-                (f"~{args.agents} agents/GPU sustained by {n_sinks} source-sinks (MonotonicCrowd, lanes 1 m "
-                 f"apart, alternating direction, 1.3 m/s), Zanlungo(A=1,D=0.4,m=2,R=0.2), eyesight "
-                 f"{args.eyesight} m, cell {args.cell} m, dt 0.05 s"),
+                "workload": desc,
+                "workload_name": args.workload,
                 "readback": "every step, 32 B/agent to pinned host memory" if args.readback else "none",
                 "planner": args.planner,
                 "n_spawned_last_step": rep.get("n_spawned"), "n_destroyed_last_step": rep.get("n_destroyed"),
-                "agents_per_gpu": args.agents, "eyesight": args.eyesight, "cell": args.cell,
+                "agents_per_gpu": per_gpu, "agents_total": total_agents, "eyesight": args.eyesight, "cell": args.cell,
                 "speed": speed, "kernel": args.kernel,
                 "parallelism": "1 GPU" if world == 1 else
                 f"{tiling[0]}x{tiling[1]} spatial tiles, one per GPU, one halo exchange with the (up to) 8 neighbours over "
                 f"{backend} send/recv",
-                "n_tti_zero": rep["n_tti_zero"], "n_nonfinite": rep["n_nonfinite"],
-                "n_agents_alive": rep["n_agents"],
+                "n_tti_zero": int(t_n[1].item()), "n_nonfinite": int(t_n[2].item()),
+                "n_agents_alive": alive_all,
+                "profile_key": key,
                 **tile_report,
             },
             "roofline": {
+                # the nominal bound of a neighbour gather, with SURVEY.md section 8(d)'s algorithmic bytes
+                # (48 B per agent + 8 B per cell)
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "note": "HBM is the nominal bound of a neighbour gather; the kernel is VALU-issue / "
-                        "LDS-latency bound at this neighbour count (DESIGN.md section 4)",
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
                 "kernel_ms": k4_ms, "kernel_launches_timed": k4["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
-                # what actually bounds it: wave64 VALU instructions (PMC, profiles/r01) against the
-                # chip's issue rate of one per 2 clocks per SIMD (1024 SIMDs, 2.4 GHz)
-                "valu_issue_frac": (valu_insts / (k4_ms * 1e-3) / (1024 * 2.4e9 / 2.0))
-                if (valu_insts and k4_ms > 0) else None,
+                "algorithmic_bytes": "SURVEY.md 8(d): 32 B read + 16 B written per agent, 8 B per cell",
+                "fused_kernel_bytes_per_launch": fused_bytes,
+                # what actually bounds it: wave64 VALU instructions per launch (PMC) against the chip's
+                # issue rate of one per 2 clocks per SIMD (1024 SIMDs, 2.4 GHz)
+                "bound_actual": "valu_issue",
+                "valu_issue_frac": valu_frac,
+                "valu_wave_insts_per_launch": valu_insts,
+                "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+                "pmc_source": pmc_source,
+                "note": "HBM is the nominal bound of a neighbour gather; at ~31 neighbours per agent the kernel is "
+                        "bound by VALU issue and LDS latency (DESIGN.md section 4); traffic / valu_* are null unless a "
+                        "PMC summary taken on exactly these sources and this workload is cached under profiles/",
             },
         }
+        if creep_leg:
+            out["creep_scene"] = creep_leg
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.agents, args.cell, args.eyesight, speed)
-            if args.workload == "uniform":
+            wl = args.workload if uniform_kind else "creep"
+            out["cpu_baseline"] = cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)
+            if uniform_kind:
                 # a second, stronger CPU number (not the reference's shape), for orientation
-                out["cpu_baseline_openmp"] = cpu_baseline_openmp(args.agents, args.cell, args.eyesight, speed)
+                out["cpu_baseline_openmp"] = cpu_baseline_openmp(per_gpu, args.cell, args.eyesight, speed, workload=wl)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -81,14 +81,15 @@ WALK_SPEED = 1.3      # m/s
 CREEP_SPEED = 0.001
 
 
-def uniform_crowd(n, seed=7, density=METRIC_DENSITY, cell_size=2.0, margin=10.0):
-    """n agents on a jittered lattice at `density`, centred in a square grid with `margin`
-    metres of free cells around the population.  Returns (positions, grid kwargs, extent,
-    group) where group[k] in {0, 1} is a checkerboard over lattice sites."""
+def uniform_crowd(n, seed=7, density=METRIC_DENSITY, cell_size=2.0, margin=10.0, room=0.0):
+    """n agents on a jittered lattice at `density`, in a square grid with `margin` metres of free
+    cells around the population and `room` more metres on the high sides (for a crowd that
+    walks).  Returns (positions, grid kwargs, extent, group) where group[k] in {0, 1} is a
+    checkerboard over lattice sites."""
     spacing = 1.0 / math.sqrt(density)
     side = int(math.ceil(math.sqrt(n)))
     extent = side * spacing
-    cells = int(math.ceil((extent + 2 * margin) / cell_size))
+    cells = int(math.ceil((extent + 2 * margin + room) / cell_size))
     width = cells * cell_size
     pts = jittered_lattice(n, spacing, (margin, margin), 0.2, seed, columns=side)
     k = np.arange(n)
@@ -163,6 +164,24 @@ def add_counterflow(sim, pts, group, speed, local_planner, eyesight, axis=1):
     v[axis] = -speed
     ids[group == 1] = sim.add_agents(pts[group == 1], StubHighLevelPlan(tuple(v)), local_planner,
                                      eyesight)
+    return ids
+
+
+def add_walking_crowd(sim, pts, group, local_planner, eyesight, walk=WALK_SPEED, creep=CREEP_SPEED):
+    """The creeping counter-flow carried along at walking speed: every agent walks +x at `walk`
+    (1.3 m/s: 6.5 cm per step of 0.05 s, so ~3 % of the agents change cell every step and the
+    re-binning, the histogram and the scatter do real work), group 0 drifts +y and group 1 -y at
+    `creep` on top.  Relative velocities, hence times to collision and neighbour lists, are those of
+    the creeping scene.  The reference's force term looks |v_i| * t_i ahead (zanlungo.rs:109-111
+    with the neighbour's velocity blended to zero), hundreds of metres here, so exp(-(dist - 2R)/D)
+    underflows and v = v_pref exactly, in f64 as in f32: a crowd that walks for as long as the grid
+    lasts.  (A head-on counter-flow AT walking speed does not exist in this model for any
+    agent_scale: walkers pass through each other, t_i = 0, 0/0)
+    Returns the agent ids in the order of `pts`."""
+    from .simulation import StubHighLevelPlan
+    ids = np.zeros(len(pts), dtype=np.int64)
+    ids[group == 0] = sim.add_agents(pts[group == 0], StubHighLevelPlan((walk, creep)), local_planner, eyesight)
+    ids[group == 1] = sim.add_agents(pts[group == 1], StubHighLevelPlan((walk, -creep)), local_planner, eyesight)
     return ids
 
 

@@ -324,6 +324,33 @@ def test_creeping_counterflow_1000_steps():
     assert err <= 1e-4
 
 
+def test_walking_crowd_300_steps():
+    """bench.py's default workload in miniature (scenes.add_walking_crowd): the creeping counter-flow
+    carried along at 1.3 m/s, so every agent changes cell about ten times in 300 steps (re-binning,
+    histogram, scatter and window builder all see a moving crowd).  Engine (tiled and gather, same
+    bits) vs the f64 oracle: ids, |dp| / L <= 1e-4; the oracle certifies the scene (n_tti_zero = 0)."""
+    n = 20000
+    runs = {}
+    for name, cls, flags in (("tiled", Simulation, 2), ("gather", Simulation, 1), ("oracle", OracleSimulation, 0)):
+        pts, grid, extent, group = scenes.uniform_crowd(n, seed=13, cell_size=2.0, room=25.0)
+        sim = cls(LocationHash2D(**grid), flags=flags) if cls is Simulation else cls(LocationHash2D(**grid))
+        scenes.add_walking_crowd(sim, pts, group, Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+        tz = 0
+        for k in range(300):
+            sim.step(0.05, report=(cls is not Simulation or k % 50 == 49))
+            if cls is not Simulation:
+                tz += sim.last_report["n_tti_zero"]
+        runs[name] = (sim.read_agents(), tz, extent, pts)
+    a, g, (b, tz, extent, pts) = runs["tiled"][0], runs["gather"][0], runs["oracle"]
+    assert tz == 0 and np.isfinite(b["x"]).all()
+    assert a.tobytes() == g.tobytes()
+    err = max_rel_err(a, b, extent)
+    walked = float((b["x"] - np.sort(pts[:, 0])[0]).max())
+    print(f"walking crowd: |dp|/L = {err:.2e} after 300 steps ({19.5:.1f} m walked)")
+    assert err <= 1e-4 and walked > 19.0
+    assert np.allclose(a["vx"], scenes.WALK_SPEED, rtol=1e-6) and np.allclose(np.abs(a["vy"]), scenes.CREEP_SPEED, rtol=1e-5)
+
+
 @pytest.mark.parametrize("rows", ["2", "1", "3"])
 def test_tiled_and_gather_kernels_agree_bitwise(rows, monkeypatch):
     """rows = owned rows per workgroup of the tiled kernel (CS_TILE_ROWS): 2-row band windows (the

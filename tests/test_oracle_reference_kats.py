@@ -367,3 +367,26 @@ def test_openmp_baseline_reproduces_the_oracle_bit_for_bit():
         assert sec > 0
         assert np.array_equal(xy[:, 0], a["x"]) and np.array_equal(xy[:, 1], a["y"])
         assert np.array_equal(vel[:, 0], a["vx"]) and np.array_equal(vel[:, 1], a["vy"])
+
+
+def test_walking_scene_is_certified_on_the_oracle():
+    """bench.py's default workload (scenes.add_walking_crowd) on the f64 oracle for the full 1000
+    steps of the north star: nobody's time to collision reaches 0, nobody goes non-finite, and the
+    velocities stay the preferred ones exactly (the force term underflows, see the scene's
+    docstring), so the crowd walks 65 m."""
+    import numpy as np
+    from rmf_crowdsim_amd import LocationHash2D, Zanlungo, scenes
+    n = 1500
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0, room=70.0)
+    sim = OracleSimulation(LocationHash2D(**grid))
+    ids = scenes.add_walking_crowd(sim, pts, group, Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+    tz = 0
+    for _ in range(1000):
+        sim.step(0.05)
+        tz += sim.last_report["n_tti_zero"] + sim.last_report["n_nonfinite"]
+    a = sim.read_agents()
+    assert tz == 0 and len(a) == n
+    assert (a["vx"] == scenes.WALK_SPEED).all() and (np.abs(a["vy"]) == scenes.CREEP_SPEED).all()
+    start = np.empty_like(pts)
+    start[ids] = pts
+    assert np.allclose(a["x"] - start[:, 0], 65.0, atol=1e-9)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over the bench workload; summaries land in gpurun_out/prof_<tag>/
 tag=${1:-r01}; shift
-args=${@:-"--steps 20 --warmup 5 --no-cpu-baseline"}
+args=${@:-"--steps 20 --warmup 5 --no-cpu-baseline --no-creep-leg"}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
@@ -15,6 +15,7 @@ find $out -name "*.csv" | head -20
 python3 - <<PY
 import csv, glob, collections, os
 out="$out"
+k4={}
 for f in glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True):
     print(open(f).read()[:3000])
 for tag in ("pmc1","pmc2","pmc3","pmc4"):
@@ -28,4 +29,20 @@ for tag in ("pmc1","pmc2","pmc3","pmc4"):
                 for c,val in v.items():
                     line=f"{k:42s} {c:24s} per-launch {val/cnt[(k,c)]:.4g} launches {cnt[(k,c)]}"
                     print(line); w.write(line+"\n")
+                    if "k_step_tiled" in k: k4[c]=val/cnt[(k,c)]
+# the cache bench.py reads (roofline.traffic / valu_issue_frac), keyed to sources + workload
+import json
+line=json.loads(open(out+"/trace_bench.json").read().strip().splitlines()[-1])
+fetch, write = k4.get("FETCH_SIZE"), k4.get("WRITE_SIZE")
+summary={"command": "python bench.py $args (rocprofv3 --pmc, separate passes; tools/rocprof_passes.sh $tag)",
+         "profile_key": line["config"]["profile_key"], "workload": line["config"]["workload"],
+         "kernel": "k_step_tiled",
+         "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write, "fetch_correction": 2.0,
+         "traffic_bytes_per_launch": int((2.0*fetch+write)*1024) if fetch and write else None,
+         "valu_wave_insts_per_launch": k4.get("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": k4.get("SQ_INSTS_SALU"),
+         "lds_wave_insts_per_launch": k4.get("SQ_INSTS_LDS"), "wave_quad_cycles_per_launch": k4.get("SQ_WAVE_CYCLES"),
+         "lds_bank_conflict_cycles_per_launch": k4.get("SQ_LDS_BANK_CONFLICT"),
+         "kernel_ms_in_this_run": line["roofline"]["kernel_ms"]}
+json.dump(summary, open(out+"/k4_traffic.json","w"), indent=1)
+print(json.dumps(summary))
 PY
