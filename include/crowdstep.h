@@ -350,6 +350,29 @@ int cs_spawn_commit(cs_engine*, const uint8_t* flags, size_t n);
 int cs_spawn_probe_dev(cs_engine*, double dt_seconds, int* flags_dev, size_t cap);
 int cs_spawn_commit_dev(cs_engine*, const int* flags_dev, size_t n);
 
+/* ---- tiles: the transport itself, over RCCL ------------------------------ */
+/* The halo exchange and the spawn-flag all-reduce without any help from the host's runtime: the
+ * engine binds RCCL (librccl.so.1: the copy already in the process, else the system's) at first
+ * use and issues ncclSend / ncclRecv / ncclAllReduce on ITS stream, between cs_halo_pack_all and
+ * cs_halo_unpack_all.  One communicator per engine: rank 0 calls cs_rccl_unique_id and hands the
+ * 128 bytes to the other ranks by whatever means the host has (MPI, a file, torch.distributed),
+ * every rank then calls cs_rccl_comm_init (collective, like ncclCommInitRank); or the host adopts a
+ * communicator it already owns.  cs_halo_set_peers names the rank behind each direction
+ * (CS_DIR_*; -1 = no neighbour).  Messages are the fixed-capacity buffers of cs_halo_set_buffers
+ * (the record count travels in the header), so no size exchange precedes them. */
+#define CS_RCCL_UNIQUE_ID_BYTES 128
+int cs_rccl_unique_id(uint8_t* out_id);
+int cs_rccl_comm_init(cs_engine*, int32_t n_ranks, int32_t rank, const uint8_t* id);
+int cs_rccl_comm_adopt(cs_engine*, void* nccl_comm); /* an ncclComm_t of the host; not destroyed by the engine */
+int cs_halo_set_peers(cs_engine*, const int32_t* peers8);
+/* ncclGroupStart; ncclSend(send buffer) + ncclRecv(recv buffer) per direction with a peer;
+ * ncclGroupEnd; all on the engine's stream.  With `axis` 0 / 1 only that pair of edge directions
+ * (the two-phase schedule), with axis < 0 all eight. */
+int cs_halo_exchange_rccl(cs_engine*, int32_t axis);
+/* max over the ranks, element by element, in place (the OR of the spawn flags of
+ * cs_spawn_probe_dev), on the engine's stream */
+int cs_allreduce_max_i32_rccl(cs_engine*, int* values_dev, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1014,6 +1014,27 @@ int cs_spawn_commit_dev(cs_engine* e, const int*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_rccl_unique_id(uint8_t*) { return 8; }
+int cs_rccl_comm_init(cs_engine* e, int32_t, int32_t, const uint8_t*) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_rccl_comm_adopt(cs_engine* e, void*) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_halo_set_peers(cs_engine* e, const int32_t*) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_halo_exchange_rccl(cs_engine* e, int32_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_allreduce_max_i32_rccl(cs_engine* e, int*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 
 // Oracle-only probes used by tests/test_oracle_reference_kats.py to pin the
 // private pieces the reference's own unit tests reach (zanlungo.rs:225-236).

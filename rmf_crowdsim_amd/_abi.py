@@ -21,6 +21,7 @@ KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo"]
 CS_DIR_XLO, CS_DIR_XHI, CS_DIR_YLO, CS_DIR_YHI = 0, 1, 2, 3
 CS_DIR_XLO_YLO, CS_DIR_XLO_YHI, CS_DIR_XHI_YLO, CS_DIR_XHI_YHI = 4, 5, 6, 7
 CS_HALO_RECORD_BYTES = 40
+CS_RCCL_UNIQUE_ID_BYTES = 128
 NO_SOURCE_SINK = 0xFFFFFFFF
 
 
@@ -146,6 +147,12 @@ SYMBOLS = {
     "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
     "cs_spawn_probe_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]),
     "cs_spawn_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cs_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "cs_rccl_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "cs_rccl_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cs_halo_set_peers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "cs_halo_exchange_rccl": (C.c_int, [C.c_void_p, C.c_int32]),
+    "cs_allreduce_max_i32_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 

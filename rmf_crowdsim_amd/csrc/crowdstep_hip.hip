@@ -13,6 +13,7 @@
 //                             (location_hash_2d.rs:240-258, zanlungo.rs:49-217, lib.rs:259-359)
 //   cs_kernels_aux.hip.inc    k_halo_pack/unpack (tiles), k_spawn (lib.rs:199-254), radius query
 //   cs_engine.hip.inc         the host engine: step state machine, tables, tiles, events
+//   cs_rccl.hip.inc           RCCL bound at first use (halo transport of a tile)
 //   this file                 includes + the extern "C" boundary
 //
 // Device state is f32 and CELL-RELATIVE: an agent is (stored cell, offset from
@@ -42,6 +43,7 @@
 #include "cs_kernels_step.hip.inc"
 #include "cs_kernels_aux.hip.inc"
 #include "cs_engine.hip.inc"
+#include "cs_rccl.hip.inc"
 
 // ===========================================================================
 // C ABI (include/crowdstep.h)
@@ -54,6 +56,7 @@ void cs_destroy(cs_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->rccl_comm && e->rccl_comm_owned && rccl_api::api().comm_destroy) rccl_api::api().comm_destroy(e->rccl_comm);
   e->free_arrays(e->buf[0]);
   e->free_arrays(e->buf[1]);
   hipFree(e->pref); hipFree(e->cell_count); hipFree(e->cell_start); hipFree(e->block_totals);
@@ -632,6 +635,98 @@ int cs_halo_unpack(cs_engine* e, uint32_t axis) {
     return 3;
   }
   return e->halo_unpack(axis);
+}
+
+// ---- the transport itself, over RCCL (cs_rccl.hip.inc) ----
+int cs_rccl_unique_id(uint8_t* out_id) {
+  rccl_api::Api& a = rccl_api::api();
+  if (!a.handle || !out_id) return 8;
+  rccl_api::UniqueId id;
+  if (a.get_unique_id(&id) != 0) return 8;
+  std::memcpy(out_id, id.internal, CS_RCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int cs_rccl_comm_init(cs_engine* e, int32_t n_ranks, int32_t rank, const uint8_t* id) {
+  hipSetDevice(e->device);
+  rccl_api::Api& a = rccl_api::api();
+  if (!a.handle) {
+    e->error = a.why;
+    return 8;
+  }
+  if (!e->tile || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+    e->error = "cs_rccl_comm_init needs a tile engine, a unique id and 0 <= rank < n_ranks";
+    return 3;
+  }
+  if (e->rccl_comm && e->rccl_comm_owned) a.comm_destroy(e->rccl_comm);
+  e->rccl_comm = nullptr;
+  rccl_api::UniqueId uid;
+  std::memcpy(uid.internal, id, CS_RCCL_UNIQUE_ID_BYTES);
+  rccl_api::Comm comm = nullptr;
+  if (!rccl_api::ok(e, a.comm_init_rank(&comm, n_ranks, uid, rank), "ncclCommInitRank")) return 8;
+  e->rccl_comm = comm;
+  e->rccl_comm_owned = true;
+  return 0;
+}
+
+int cs_rccl_comm_adopt(cs_engine* e, void* nccl_comm) {
+  rccl_api::Api& a = rccl_api::api();
+  if (!a.handle) {
+    e->error = a.why;
+    return 8;
+  }
+  if (e->rccl_comm && e->rccl_comm_owned) a.comm_destroy(e->rccl_comm);
+  e->rccl_comm = nccl_comm;
+  e->rccl_comm_owned = false;
+  return 0;
+}
+
+int cs_halo_set_peers(cs_engine* e, const int32_t* peers8) {
+  if (!e->tile || !peers8) {
+    e->error = "cs_halo_set_peers needs a tile engine and eight ranks (-1 = no neighbour)";
+    return 3;
+  }
+  for (int d = 0; d < 8; ++d) e->halo_peer[d] = peers8[d];
+  return 0;
+}
+
+int cs_halo_exchange_rccl(cs_engine* e, int32_t axis) {
+  hipSetDevice(e->device);
+  rccl_api::Api& a = rccl_api::api();
+  if (!a.handle || !e->rccl_comm) {
+    e->error = a.handle ? "no RCCL communicator: call cs_rccl_comm_init or cs_rccl_comm_adopt first" : a.why;
+    return 8;
+  }
+  const int d0 = axis < 0 ? 0 : 2 * axis, d1 = axis < 0 ? 8 : 2 * axis + 2;
+  if (axis > 1) {
+    e->error = "cs_halo_exchange_rccl: axis is 0, 1 or negative (all eight directions)";
+    return 3;
+  }
+  e->prof_begin(CS_K_HALO);
+  bool good = rccl_api::ok(e, a.group_start(), "ncclGroupStart");
+  for (int d = d0; good && d < d1; ++d) {
+    const cs_engine::HaloDir& h = e->halo[d];
+    if (!h.send || !h.recv || e->halo_peer[d] < 0) continue;
+    const size_t bytes = ((size_t)h.cap + 1u) * sizeof(HaloRecord);
+    good = rccl_api::ok(e, a.send(h.send, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, e->stream), "ncclSend") &&
+           rccl_api::ok(e, a.recv(h.recv, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, e->stream), "ncclRecv");
+  }
+  const int end_rc = a.group_end();  // always close the group
+  e->prof_end();
+  if (!good) return 8;
+  return rccl_api::ok(e, end_rc, "ncclGroupEnd") ? 0 : 8;
+}
+
+int cs_allreduce_max_i32_rccl(cs_engine* e, int* values_dev, size_t n) {
+  hipSetDevice(e->device);
+  rccl_api::Api& a = rccl_api::api();
+  if (!a.handle || !e->rccl_comm) {
+    e->error = a.handle ? "no RCCL communicator: call cs_rccl_comm_init or cs_rccl_comm_adopt first" : a.why;
+    return 8;
+  }
+  if (n == 0) return 0;
+  return rccl_api::ok(e, a.all_reduce(values_dev, values_dev, n, rccl_api::kInt32, rccl_api::kMax, e->rccl_comm, e->stream),
+                      "ncclAllReduce") ? 0 : 8;
 }
 
 }  // extern "C"

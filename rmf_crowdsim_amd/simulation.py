@@ -536,6 +536,32 @@ class Simulation:
         if self._lib.cs_halo_unpack_all(self._engine) != 0:
             raise self._err()
 
+    # -- tiles: the RCCL transport of the C ABI (cs_rccl_*, cs_halo_exchange_rccl) --
+    def rccl_unique_id(self):
+        """Rank 0: the 128 bytes every rank passes to rccl_comm_init (ncclGetUniqueId)."""
+        buf = (C.c_uint8 * _abi.CS_RCCL_UNIQUE_ID_BYTES)()
+        if self._lib.cs_rccl_unique_id(buf) != 0:
+            raise CrowdSimError("RCCL is not available (librccl.so.1)")
+        return bytes(buf)
+
+    def rccl_comm_init(self, n_ranks, rank, unique_id):
+        buf = (C.c_uint8 * _abi.CS_RCCL_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        if self._lib.cs_rccl_comm_init(self._engine, int(n_ranks), int(rank), buf) != 0:
+            raise self._err()
+
+    def halo_set_peers(self, peers):
+        arr = (C.c_int32 * 8)(*[int(p) for p in peers])
+        if self._lib.cs_halo_set_peers(self._engine, arr) != 0:
+            raise self._err()
+
+    def halo_exchange_rccl(self, axis=-1):
+        if self._lib.cs_halo_exchange_rccl(self._engine, int(axis)) != 0:
+            raise self._err()
+
+    def allreduce_max_rccl(self, dev_ptr, n):
+        if self._lib.cs_allreduce_max_i32_rccl(self._engine, C.c_void_p(dev_ptr), int(n)) != 0:
+            raise self._err()
+
     def spawn_probe(self, dur):
         """Tile engines: which of MY source-sinks would spawn this step (uint8 flag per sink)."""
         dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)

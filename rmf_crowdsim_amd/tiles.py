@@ -347,7 +347,12 @@ class DistributedTiles(_TileBase):
     """One tile per rank (rank == tile index) under an initialised torch.distributed group."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device, capacity_records=None,
-                 density_per_cell=16.0, capacity_hint=0, flags=0, weights=None, phases=1):
+                 density_per_cell=16.0, capacity_hint=0, flags=0, weights=None, phases=1, transport=None):
+        """transport: "engine" = the C ABI's own RCCL transport (cs_halo_exchange_rccl: ncclSend /
+        ncclRecv issued by the engine on its stream, what a Rust or C++ host uses), "torch" =
+        torch.distributed batch_isend_irecv.  Default: "engine" on the nccl backend (CS_TILES_TRANSPORT
+        overrides), "torch" otherwise (the gloo test double moves host memory)."""
+        import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -371,6 +376,17 @@ class DistributedTiles(_TileBase):
             self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
             self.bufs[d] = (send, recv)
         self._op_cache = {} if dist.get_backend() == "nccl" else None
+        if transport is None:
+            transport = os.environ.get("CS_TILES_TRANSPORT", "engine" if dist.get_backend() == "nccl" else "torch")
+        self.transport = transport
+        if transport == "engine":
+            # one RCCL communicator per engine: rank 0's unique id reaches the others through the
+            # process group that already exists; from then on the halo traffic needs no torch
+            box = [self.sim.rccl_unique_id() if self.index == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.sim.rccl_comm_init(dist.get_world_size(), self.index, box[0])
+            peers = [self.layout.neighbour(tx, ty, d) for d in ALL_DIRS]
+            self.sim.halo_set_peers([-1 if (p is None or d not in self.bufs) else p for p, d in zip(peers, ALL_DIRS)])
         torch.cuda.synchronize(dev)
 
     def add_agents(self, positions, high_level_planner, local_planner, eyesight):
@@ -413,11 +429,17 @@ class DistributedTiles(_TileBase):
             if self.phases == 2:
                 for axis in (0, 1):
                     self.sim.halo_pack(axis)
-                    exchange_axis(self.dist, self.layout, self.index, self.bufs, axis, self._op_cache)
+                    if self.transport == "engine":
+                        self.sim.halo_exchange_rccl(axis)
+                    else:
+                        exchange_axis(self.dist, self.layout, self.index, self.bufs, axis, self._op_cache)
                     self.sim.halo_unpack(axis)
             else:
                 self.sim.halo_pack_all()
-                exchange_all(self.dist, self.layout, self.index, self.bufs, self._op_cache)
+                if self.transport == "engine":
+                    self.sim.halo_exchange_rccl(-1)
+                else:
+                    exchange_all(self.dist, self.layout, self.index, self.bufs, self._op_cache)
                 self.sim.halo_unpack_all()
         if getattr(self, "_has_sinks", False):
             # Ids follow the global sink order: OR the per-tile spawn flags.  Whether a rank probes
@@ -446,7 +468,9 @@ class DistributedTiles(_TileBase):
 
     def _allreduce_max(self, t):
         """MAX over the ranks of a device tensor, on the engine's stream."""
-        if self.dist.get_backend() == "nccl":
+        if self.transport == "engine":
+            self.sim.allreduce_max_rccl(t.data_ptr(), t.numel())
+        elif self.dist.get_backend() == "nccl":
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         else:  # test transport (ranks sharing one GPU): gloo moves host memory
             host = t.cpu()

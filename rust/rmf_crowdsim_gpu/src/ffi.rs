@@ -48,6 +48,7 @@ pub const CS_DIR_XLO_YHI: u32 = 5;
 pub const CS_DIR_XHI_YLO: u32 = 6;
 pub const CS_DIR_XHI_YHI: u32 = 7;
 pub const CS_HALO_RECORD_BYTES: u32 = 40;
+pub const CS_RCCL_UNIQUE_ID_BYTES: usize = 128;
 
 /// Opaque engine handle (`struct cs_engine`).
 #[repr(C)]
@@ -219,4 +220,10 @@ extern "C" {
     pub fn cs_spawn_commit(e: *mut cs_engine, flags: *const u8, n: usize) -> c_int;
     pub fn cs_spawn_probe_dev(e: *mut cs_engine, dt_seconds: f64, flags_dev: *mut c_int, cap: usize) -> c_int;
     pub fn cs_spawn_commit_dev(e: *mut cs_engine, flags_dev: *const c_int, n: usize) -> c_int;
+    pub fn cs_rccl_unique_id(out_id: *mut u8) -> c_int;
+    pub fn cs_rccl_comm_init(e: *mut cs_engine, n_ranks: i32, rank: i32, id: *const u8) -> c_int;
+    pub fn cs_rccl_comm_adopt(e: *mut cs_engine, nccl_comm: *mut c_void) -> c_int;
+    pub fn cs_halo_set_peers(e: *mut cs_engine, peers8: *const i32) -> c_int;
+    pub fn cs_halo_exchange_rccl(e: *mut cs_engine, axis: i32) -> c_int;
+    pub fn cs_allreduce_max_i32_rccl(e: *mut cs_engine, values_dev: *mut c_int, n: usize) -> c_int;
 }

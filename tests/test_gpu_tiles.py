@@ -374,12 +374,55 @@ def _rank_nccl_single(port, out_path):
                     work.wait()
                 ok = ok and bool((recv == k).all().item())
         grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
-        tiles = DistributedTiles(LocationHash2D(**grid), (1, 1), halo_cells=1, device=0)
-        _sink_scene(tiles)
-        for k in range(400):
-            tiles.step(0.05, report=(k in (150, 151)))  # flags all-reduced on the device, twice via the host
+        results = {}
+        for transport in ("engine", "torch"):
+            tiles = DistributedTiles(LocationHash2D(**grid), (1, 1), halo_cells=1, device=0, transport=transport)
+            assert tiles.transport == transport
+            _sink_scene(tiles)
+            for k in range(400):
+                tiles.step(0.05, report=(k in (150, 151)))  # flags all-reduced on the device, twice via the host
+            results[transport] = tiles.read_agents()
+        # The C ABI's RCCL transport moving real halo buffers: a tile in the middle of the grid (ghost
+        # rings on both x sides) exchanges with ITSELF, the XLO and XHI send buffers landing in the
+        # XLO and XHI receive buffers (self sends match self receives in order).  Through
+        # cs_halo_exchange_rccl as through torch's batch_isend_irecv, what arrives is what was packed
+        # (the order of the records in a buffer differs from run to run: they are appended with atomics).
+        from rmf_crowdsim_amd import Simulation, StubHighLevelPlan, Zanlungo, scenes
+        from rmf_crowdsim_amd.tiles import RECORD, XHI, XLO
+        recv_bytes = {}
+        for transport in ("engine", "torch"):
+            with torch.cuda.stream(side):
+                sim = Simulation(LocationHash2D(**grid), device=0, stream=side.cuda_stream, tile=(10, 20, 0, 30),
+                                 halo_cells=1)
+                cap = 4096
+                bufs = {d: (torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda"),
+                            torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda")) for d in (XLO, XHI)}
+                for d, (s_, r_) in bufs.items():
+                    sim.halo_set_buffers(d, s_.data_ptr(), r_.data_ptr(), cap)
+                pts = scenes.jittered_lattice(2000, 0.63, (15.0, 5.0), 0.2, 3)
+                sim.add_agents(pts, StubHighLevelPlan((0.0, 0.0)), Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+                sim.halo_pack_all()
+                if transport == "engine":
+                    sim.rccl_comm_init(1, 0, sim.rccl_unique_id())
+                    sim.halo_set_peers([0, 0, -1, -1, -1, -1, -1, -1])
+                    sim.halo_exchange_rccl(-1)
+                else:
+                    ops = []
+                    for d in (XLO, XHI):
+                        ops += [dist.P2POp(dist.isend, bufs[d][0], 0), dist.P2POp(dist.irecv, bufs[d][1], 0)]
+                    for work in dist.batch_isend_irecv(ops):
+                        work.wait()
+                side.synchronize()
+                recv_bytes[transport] = all(bufs[d][1].cpu().numpy().tobytes() == bufs[d][0].cpu().numpy().tobytes()
+                                            for d in (XLO, XHI))
+                sent = [int(bufs[d][0][:4].cpu().numpy().view("<u4")[0]) for d in (XLO, XHI)]
+                recv_bytes[transport] = recv_bytes[transport] and min(sent) > 20
+        checks = {"stream_order": ok, "mesh_engine_vs_torch": results["engine"].tobytes() == results["torch"].tobytes(),
+                  "self_exchange_engine": recv_bytes["engine"], "self_exchange_torch": recv_bytes["torch"]}
+        print("rccl checks:", checks, "records sent", sent, flush=True)
+        ok = all(checks.values())
         with open(out_path, "wb") as f:
-            pickle.dump((ok, tiles.read_agents()), f)
+            pickle.dump((ok, results["engine"]), f)
     finally:
         dist.destroy_process_group()
 
