@@ -278,6 +278,10 @@ size_t cs_query_radius(cs_engine*, double radius, double x, double y,
 /* SpatialIndex::get_nearest_neighbours                  location_hash_2d.rs:151-238 */
 size_t cs_query_knn(cs_engine*, size_t k, double x, double y, uint64_t* out_ids);
 
+/* Device memory the engine holds, in bytes.  It grows with the agent CAPACITY (slots), the grid and
+ * the number of source-sinks and routes, never with the number of steps or of ids handed out. */
+uint64_t cs_device_bytes(cs_engine*);
+
 /* ---- measurement (bench.py / rocprof cross-check) ---------------------- */
 /* Kernel names the engine launches per step, for HIP-event timing. */
 enum {

@@ -893,6 +893,7 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
 }
 void cs_remove_source_sink(cs_engine* e, uint32_t handle) { e->source_sinks.erase(handle); }
 size_t cs_source_sink_slots(cs_engine* e) { return e->next_sink_handle; }
+uint64_t cs_device_bytes(cs_engine*) { return 0; }
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
   const int rc = e->step(dt_seconds, report);

@@ -119,6 +119,7 @@ SYMBOLS = {
     "cs_add_source_sink": (C.c_uint32, [C.c_void_p, C.POINTER(SourceSinkDesc)]),
     "cs_remove_source_sink": (None, [C.c_void_p, C.c_uint32]),
     "cs_source_sink_slots": (C.c_size_t, [C.c_void_p]),
+    "cs_device_bytes": (C.c_uint64, [C.c_void_p]),
     "cs_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
     "cs_synchronize": (C.c_int, [C.c_void_p]),
     "cs_agent_count": (C.c_size_t, [C.c_void_p]),

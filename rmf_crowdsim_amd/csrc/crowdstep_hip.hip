@@ -68,7 +68,7 @@ void cs_destroy(cs_engine* e) {
     if (sn.copied) hipEventDestroy(sn.copied);
   }
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
-  hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_state_dev); hipFree(e->route_pending_dev);
+  hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
   hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev);
@@ -292,6 +292,7 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
 }
 
 size_t cs_source_sink_slots(cs_engine* e) { return e->sinks.size(); }
+uint64_t cs_device_bytes(cs_engine* e) { return e->device_bytes(); }
 
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   if (e->groups.size() + 1 >= CS_MAX_GROUPS || d->n_waypoints == 0 || d->n_waypoints > 65535) {

@@ -574,6 +574,11 @@ class Simulation:
         return flags[:n]
 
     @property
+    def device_bytes(self):
+        """Device memory held by the engine (grows with capacity, never with steps or ids)."""
+        return int(self._lib.cs_device_bytes(self._engine))
+
+    @property
     def source_sink_slots(self):
         """Source-sink handles handed out so far (removed sinks keep their slot)."""
         return int(self._lib.cs_source_sink_slots(self._engine))

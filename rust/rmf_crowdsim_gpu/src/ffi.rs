@@ -197,6 +197,7 @@ extern "C" {
     pub fn cs_add_source_sink(e: *mut cs_engine, d: *const cs_source_sink_desc) -> u32;
     pub fn cs_remove_source_sink(e: *mut cs_engine, handle: u32);
     pub fn cs_source_sink_slots(e: *mut cs_engine) -> usize;
+    pub fn cs_device_bytes(e: *mut cs_engine) -> u64;
     pub fn cs_step(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
     pub fn cs_synchronize(e: *mut cs_engine) -> c_int;
     pub fn cs_agent_count(e: *mut cs_engine) -> usize;

@@ -14,7 +14,7 @@ import pytest
 from oracle_sim import OracleSimulation
 from rmf_crowdsim_amd import (CrowdSimError, IdParityHighLevelPlan, LocationHash2D, MonotonicCrowd,
                               NoLocalPlan, SeededPoissonCrowd, Simulation, SourceSink,
-                              StubHighLevelPlan, Zanlungo, HighLevelPlanner)
+                              StubHighLevelPlan, Zanlungo, HighLevelPlanner, RouteFollower)
 from rmf_crowdsim_amd import scenes
 from test_oracle_reference_kats import MockEventListener, run_event_listener_source_sink_api
 
@@ -779,6 +779,29 @@ def test_streaming_snapshots_match_the_oracle():
     ora.request_snapshot()
     s, step = ora.snapshot()
     assert step == 60 and len(s) == len(ora)
+
+
+def test_a_long_stream_of_route_followers_holds_constant_device_memory():
+    """200,000 steps of a miniature source-sink stream of route followers: 67,000 ids are handed out,
+    a few dozen agents are alive at any time.  The agent_cache entry travels with the agent (4 B per
+    agent SLOT), so the engine's device memory is the same after 200,000 steps as after 2,000 (it
+    used to be indexed by agent id and grew by 4 B per id, 16 KB per step on BASELINE configs[3])."""
+    sim = Simulation(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)))
+    hlp = RouteFollower(lambda start, goal: [start, goal], scale=0.5, speed=1.3)
+    for k in range(4):
+        sim.add_source_sink(SourceSink((5.0, 5.0 + 8.0 * k), 0.5, MonotonicCrowd(1000.0), hlp, NoLocalPlan(),
+                                       [(9.0, 5.0 + 8.0 * k)], False, 2.0))
+    for _ in range(2000):
+        sim.step(0.05, report=False)
+    sim.synchronize()
+    early, n_early = sim.device_bytes, len(sim)
+    for _ in range(198_000):
+        sim.step(0.05, report=False)
+    a = sim.read_agents()
+    print(f"stream: {len(a)} alive, highest id {int(a['id'].max())}, device bytes {early} -> {sim.device_bytes}")
+    assert sim.device_bytes == early and early < 4_000_000
+    assert len(a) == n_early and a["id"].max() > 60_000
+    assert np.allclose(a["vx"], 1.3, rtol=1e-6) and np.isfinite(a["x"]).all()
 
 
 def test_three_way_parity_isolates_rounding_from_kernel_errors():
