@@ -220,9 +220,9 @@ int cs_add_agents(cs_engine*, const double* xy, size_t n, uint32_t hlp,
  *                                                               lib.rs:176-192 */
 int cs_remove_agent(cs_engine*, uint64_t id);
 /* Simulation::add_source_sink / remove_source_sink              lib.rs:159-168
- * Returns the handle, or UINT32_MAX (cs_last_error says why).  On a tile engine a sink whose
- * planner is CS_HLP_ROUTE must have exactly one waypoint; its route is planned here (route_plan
- * is called once per tile, in registration order) so that every tile numbers routes alike. */
+ * Returns the handle, or UINT32_MAX (cs_last_error says why).  On a tile engine the first leg of a
+ * sink whose planner is CS_HLP_ROUTE is planned here (route_plan is called once per tile, in
+ * registration order) so that every tile numbers routes alike; see cs_route_resolve for later legs. */
 uint32_t cs_add_source_sink(cs_engine*, const cs_source_sink_desc*);
 void cs_remove_source_sink(cs_engine*, uint32_t handle);
 /* Number of source-sink handles ever handed out (registry.rs:16-21: ids only grow; a removed
@@ -353,6 +353,23 @@ int cs_spawn_commit(cs_engine*, const uint8_t* flags, size_t n);
  * callback planners and per-step reports; the host-side pair above remains for those. */
 int cs_spawn_probe_dev(cs_engine*, double dt_seconds, int* flags_dev, size_t cap);
 int cs_spawn_commit_dev(cs_engine*, const int* flags_dev, size_t n);
+
+/* Route followers (CS_HLP_ROUTE) on tiles.  Route numbers travel in halo records, so every tile's
+ * route book must number routes alike.  Legs after the first start wherever an agent stands when it
+ * reaches a waypoint (set_target, lib.rs:325-333 -> rmf/mod.rs:217-236): the step kernel answers
+ * them from the book; a (start, goal) pair the book lacks is a MISS.  After cs_step the host collects
+ * the misses of all tiles (cs_route_misses; with out == NULL just their number), sorts them by agent
+ * id (the reference's canonical visiting order) and hands the merged list to EVERY tile
+ * (cs_route_resolve): each plans the new routes in that order and assigns them to the agents it holds. */
+typedef struct cs_route_miss {
+  uint64_t id;   /* agent */
+  uint32_t hlp;  /* planner handle */
+  uint32_t slot; /* where the reporting tile holds the agent (opaque to other tiles) */
+  double px, py; /* agent position: the start of the leg */
+  double tx, ty; /* the waypoint: the goal of the leg */
+} cs_route_miss;
+size_t cs_route_misses(cs_engine*, cs_route_miss* out, size_t cap);
+int cs_route_resolve(cs_engine*, const cs_route_miss* all, size_t n);
 
 /* ---- tiles: the transport itself, over RCCL ------------------------------ */
 /* The halo exchange and the spawn-flag all-reduce without any help from the host's runtime: the

@@ -1015,6 +1015,11 @@ int cs_spawn_commit_dev(cs_engine* e, const int*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+size_t cs_route_misses(cs_engine*, cs_route_miss*, size_t) { return 0; }
+int cs_route_resolve(cs_engine* e, const cs_route_miss*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 int cs_rccl_unique_id(uint8_t*) { return 8; }
 int cs_rccl_comm_init(cs_engine* e, int32_t, int32_t, const uint8_t*) {
   e->error = "oracle has no tiles";

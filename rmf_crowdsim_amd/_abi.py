@@ -83,6 +83,11 @@ class SourceSinkDesc(C.Structure):
                 ("loop_forever", C.c_int32), ("agent_eyesight_range", C.c_double)]
 
 
+class RouteMiss(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("hlp", C.c_uint32), ("slot", C.c_uint32), ("px", C.c_double),
+                ("py", C.c_double), ("tx", C.c_double), ("ty", C.c_double)]
+
+
 class StepReport(C.Structure):
     _fields_ = [("n_agents", C.c_uint64), ("n_spawned", C.c_uint64), ("n_destroyed", C.c_uint64),
                 ("n_waypoint_hits", C.c_uint64), ("n_tti_zero", C.c_uint64),
@@ -148,6 +153,8 @@ SYMBOLS = {
     "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
     "cs_spawn_probe_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]),
     "cs_spawn_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cs_route_misses": (C.c_size_t, [C.c_void_p, C.POINTER(RouteMiss), C.c_size_t]),
+    "cs_route_resolve": (C.c_int, [C.c_void_p, C.POINTER(RouteMiss), C.c_size_t]),
     "cs_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "cs_rccl_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "cs_rccl_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -306,13 +306,10 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   uint32_t handle = (uint32_t)e->sinks.size();
   if (e->tile && d->hlp < e->hlps.size() && e->hlps[d->hlp].kind == CS_HLP_ROUTE) {
     // A tile cannot ask its host for a route in the middle of a step and stay in step with its
-    // neighbours: the route book is filled here, in sink order, the same on every tile (halo
-    // records carry route numbers).  Later legs start wherever an agent stands, so they cannot
-    // be planned ahead.
-    if (d->n_waypoints != 1) {
-      e->error = "route followers on a tile engine take source-sinks with one waypoint";
-      return UINT32_MAX;
-    }
+    // neighbours: the first leg's route is put into the book here, in sink order, the same on
+    // every tile (halo records carry route numbers).  Later legs start wherever an agent stands:
+    // they are answered from the book on the device, and what misses it comes back through
+    // cs_route_misses / cs_route_resolve after the step, merged over all tiles by the host.
     s.spawn_route = e->route_lookup(d->hlp, d->source_x, d->source_y, s.waypoints[0], s.waypoints[1]);
     if (!s.spawn_route) {
       e->error = "route planner found no route for this source-sink (tile engines plan at registration)";
@@ -636,6 +633,31 @@ int cs_halo_unpack(cs_engine* e, uint32_t axis) {
     return 3;
   }
   return e->halo_unpack(axis);
+}
+
+// ---- route followers on tiles: keeping every tile's route book alike ----
+size_t cs_route_misses(cs_engine* e, cs_route_miss* out, size_t cap) {
+  const size_t n = std::min(cap, e->route_misses.size());
+  for (size_t k = 0; k < n && out; ++k) out[k] = e->route_misses[k];
+  return e->route_misses.size();
+}
+
+int cs_route_resolve(cs_engine* e, const cs_route_miss* all, size_t n) {
+  hipSetDevice(e->device);
+  for (size_t k = 0; k < n; ++k) {
+    const cs_route_miss& m = all[k];
+    if (m.hlp >= e->hlps.size() || e->hlps[m.hlp].kind != CS_HLP_ROUTE) {
+      e->error = "cs_route_resolve: not a route planner";
+      return 2;
+    }
+    const uint32_t st = e->route_lookup(m.hlp, m.px, m.py, m.tx, m.ty);  // plans on a miss: the book grows
+    if (!st) continue;  // "Failed to find contiguous path": the agent keeps what it had
+    for (const cs_route_miss& mine : e->route_misses)
+      if (mine.id == m.id) e->route_pending.push_back(make_uint2(mine.slot, st));
+  }
+  e->route_misses.clear();
+  if (int rc = e->flush_route_tables()) return rc;
+  return e->flush_route_pending();
 }
 
 // ---- the transport itself, over RCCL (cs_rccl.hip.inc) ----

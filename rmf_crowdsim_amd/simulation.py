@@ -536,6 +536,22 @@ class Simulation:
         if self._lib.cs_halo_unpack_all(self._engine) != 0:
             raise self._err()
 
+    # -- tiles: route followers' set_target calls that missed the route book (cs_route_misses / _resolve) --
+    def route_misses(self):
+        n = self._lib.cs_route_misses(self._engine, None, 0)
+        if n == 0:
+            return []
+        buf = (_abi.RouteMiss * n)()
+        self._lib.cs_route_misses(self._engine, buf, n)
+        return [(int(m.id), int(m.hlp), int(m.slot), m.px, m.py, m.tx, m.ty) for m in buf]
+
+    def route_resolve(self, misses):
+        buf = (_abi.RouteMiss * max(len(misses), 1))()
+        for k, m in enumerate(misses):
+            buf[k] = _abi.RouteMiss(*m)
+        if self._lib.cs_route_resolve(self._engine, buf, len(misses)) != 0:
+            raise self._err()
+
     # -- tiles: the RCCL transport of the C ABI (cs_rccl_*, cs_halo_exchange_rccl) --
     def rccl_unique_id(self):
         """Rank 0: the 128 bytes every rank passes to rccl_comm_init (ncclGetUniqueId)."""

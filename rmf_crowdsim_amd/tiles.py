@@ -134,6 +134,13 @@ def _is_data_planner(source_sink):
     return isinstance(source_sink.high_level_planner, (_DataPlan, RouteFollower))
 
 
+def _has_route_legs(source_sink):
+    """A route follower's sink with several waypoints: legs after the first start wherever the agent
+    stands, so their (start, goal) pairs can miss the route book (cs_route_misses)."""
+    from .simulation import RouteFollower
+    return isinstance(source_sink.high_level_planner, RouteFollower) and len(source_sink.waypoints) > 1
+
+
 class _TileBase:
     def _make_engine(self, spatial_index, layout, index, halo_cells, device, stream, capacity_hint,
                      flags):
@@ -193,7 +200,10 @@ class LocalTileMesh(_TileBase):
             handle = sim.add_source_sink(source_sink)
         self._has_sinks = True
         self._n_sinks = getattr(self, "_n_sinks", 0) + 1
-        self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
+        self._route_legs = getattr(self, "_route_legs", False) or _has_route_legs(source_sink)
+        # (legs that may miss the route book need the host after the step: the host-side spawn path)
+        self._host_planner = (getattr(self, "_host_planner", False) or not _is_data_planner(source_sink) or
+                              self._route_legs)
         return handle
 
     def add_event_listener(self, listener):
@@ -269,6 +279,13 @@ class LocalTileMesh(_TileBase):
                     sim.spawn_commit(flags)
         for sim in self.engines:
             sim.step(dur, report=report)
+        if getattr(self, "_host_planner", False) or getattr(self, "_route_legs", False):
+            # legs of route followers that missed the route book: every tile plans them, in agent
+            # order, so that all books number routes alike (cs_route_resolve)
+            misses = sorted(m for sim in self.engines for m in sim.route_misses())
+            if misses:
+                for sim in self.engines:
+                    sim.route_resolve(misses)
 
     def read_agents(self):
         parts = [sim.read_agents() for sim in self.engines]
@@ -395,7 +412,10 @@ class DistributedTiles(_TileBase):
     def add_source_sink(self, source_sink):
         self._has_sinks = True
         self._n_sinks = getattr(self, "_n_sinks", 0) + 1
-        self._host_planner = getattr(self, "_host_planner", False) or not _is_data_planner(source_sink)
+        self._route_legs = getattr(self, "_route_legs", False) or _has_route_legs(source_sink)
+        # (legs that may miss the route book need the host after the step: the host-side spawn path)
+        self._host_planner = (getattr(self, "_host_planner", False) or not _is_data_planner(source_sink) or
+                              self._route_legs)
         return self.sim.add_source_sink(source_sink)
 
     def add_event_listener(self, listener):
@@ -465,6 +485,18 @@ class DistributedTiles(_TileBase):
                 else:
                     self.sim.spawn_commit_dev(flags.data_ptr(), n)
         self.sim.step(dur, report=report)
+        if getattr(self, "_route_legs", False):
+            # legs of route followers that missed the route book on ANY tile: all ranks plan them in
+            # agent order, so that every book numbers routes alike (cs_route_resolve)
+            mine = self.sim.route_misses()
+            count = self.torch.tensor([len(mine)], dtype=self.torch.int32)
+            if self.dist.get_backend() == "nccl":
+                count = count.to(self.stream.device)
+            self.dist.all_reduce(count, op=self.dist.ReduceOp.SUM)
+            if int(count.item()):
+                parts = [None] * self.dist.get_world_size()
+                self.dist.all_gather_object(parts, mine)
+                self.sim.route_resolve(sorted(m for part in parts for m in part))
 
     def _allreduce_max(self, t):
         """MAX over the ranks of a device tensor, on the engine's stream."""

@@ -183,6 +183,18 @@ pub struct cs_snapshot_record {
     pub next_waypoint: u32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct cs_route_miss {
+    pub id: u64,
+    pub hlp: u32,
+    pub slot: u32,
+    pub px: f64,
+    pub py: f64,
+    pub tx: f64,
+    pub ty: f64,
+}
+
 extern "C" {
     pub fn cs_abi_version() -> u32;
     pub fn cs_create(grid: *const cs_grid_desc, cfg: *const cs_device_cfg) -> *mut cs_engine;
@@ -221,6 +233,8 @@ extern "C" {
     pub fn cs_spawn_commit(e: *mut cs_engine, flags: *const u8, n: usize) -> c_int;
     pub fn cs_spawn_probe_dev(e: *mut cs_engine, dt_seconds: f64, flags_dev: *mut c_int, cap: usize) -> c_int;
     pub fn cs_spawn_commit_dev(e: *mut cs_engine, flags_dev: *const c_int, n: usize) -> c_int;
+    pub fn cs_route_misses(e: *mut cs_engine, out: *mut cs_route_miss, cap: usize) -> usize;
+    pub fn cs_route_resolve(e: *mut cs_engine, all: *const cs_route_miss, n: usize) -> c_int;
     pub fn cs_rccl_unique_id(out_id: *mut u8) -> c_int;
     pub fn cs_rccl_comm_init(e: *mut cs_engine, n_ranks: i32, rank: i32, id: *const u8) -> c_int;
     pub fn cs_rccl_comm_adopt(e: *mut cs_engine, nccl_comm: *mut c_void) -> c_int;

@@ -250,6 +250,9 @@ def _two_rank_scene(kind, target):
     if kind == "routes":
         _route_scene(target, NoLocalPlan())
         return dict(width=160.0, height=160.0), 0.1
+    if kind == "legs":  # sinks with two waypoints: second legs miss the route book now and then
+        _multi_leg_scene(target, NoLocalPlan())
+        return dict(width=160.0, height=160.0), 0.1
     import sys
     saved, mod = Zanlungo, sys.modules[__name__]
     mod.Zanlungo = lambda *a: NoLocalPlan()
@@ -260,7 +263,7 @@ def _two_rank_scene(kind, target):
     return dict(width=80.0, height=80.0), 0.1
 
 
-_TWO_RANK_GRID = {"sinks": (60.0, 0.05), "routes": (160.0, 0.1), "random": (80.0, 0.1)}
+_TWO_RANK_GRID = {"sinks": (60.0, 0.05), "routes": (160.0, 0.1), "random": (80.0, 0.1), "legs": (160.0, 0.1)}
 
 
 def _rank_sinks(rank, world, port, out_path, kind, layout):
@@ -310,7 +313,8 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
 
 
 @pytest.mark.parametrize("kind,layout,port", [("sinks", (2, 1), 29723), ("sinks", (1, 2), 29724),
-                                              ("routes", (1, 2), 29725), ("random", (2, 1), 29726)])
+                                              ("routes", (1, 2), 29725), ("random", (2, 1), 29726),
+                                              ("legs", (2, 1), 29728)])
 def test_distributed_tiles_two_ranks_with_source_sinks(tmp_path, kind, layout, port):
     """One rank per tile: the spawn flags are all-reduced between the ranks (on the device path
     through a device tensor), ids follow the global sink order; same bits as one engine.  Lanes
@@ -884,19 +888,63 @@ def test_random_route_followers_engine_oracle_and_mesh_agree(seed):
         assert sorted(listeners[0].removed) == sorted(listeners[2].removed)
 
 
-def test_route_planners_on_tiles_take_single_leg_sinks_only():
-    """Later legs start wherever the agent stands (rmf/mod.rs:217-236): they cannot be planned
-    ahead, and a tile cannot stop for its host in mid-step."""
+def _multi_leg_scene(target, lp):
+    """Lanes of route followers whose sinks have TWO waypoints (a mid point and the sink), crossing
+    the cuts of a mesh; coarse SpatialHash (4 m) against a 1 m sink radius, so the second legs of a
+    lane share a few (start, goal) hash pairs: mostly book hits on the device, a few misses."""
+    from rmf_crowdsim_amd import RouteFollower, SeededPoissonCrowd, SourceSink
+    from test_oracle_reference_kats import DoglegRoutes
+    routes = DoglegRoutes()
+    hlp = RouteFollower(routes, scale=4.0, arrive=0.1, speed=1.2)
+    for k in range(16):
+        y = 20.0 + 7.5 * k
+        left = k % 2 == 0
+        src = (20.0, y) if left else (140.0, y)
+        mid = (70.0, y + 3.0) if left else (90.0, y - 3.0)
+        dst = (120.0, y) if left else (40.0, y)
+        target.add_source_sink(SourceSink(src, 1.0, SeededPoissonCrowd(1.5, 40 + k), hlp, lp, [mid, dst], False, 2.0))
+    return routes
+
+
+@pytest.mark.parametrize("tiles,report", [((2, 2), False), ((3, 1), True)])
+def test_multi_leg_route_followers_on_a_mesh_match_engine_and_oracle(tiles, report):
+    """Route followers whose sinks have several waypoints, on a tile mesh (rmf/mod.rs:217-236 on
+    tiles).  A leg that starts where the agent stands is answered from the device's route book; the
+    pairs the book lacks come back as misses, are merged over the tiles in agent order and planned
+    by every tile alike (cs_route_misses / cs_route_resolve).  Mesh = single engine bit for bit; the
+    single engine = the oracle: ids, waypoint counters, the sequence of planned routes, positions."""
+    from oracle_sim import OracleSimulation
+    grid = dict(width=160.0, height=160.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    ora = OracleSimulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1)
+    r_single, r_ora, r_mesh = (_multi_leg_scene(t, NoLocalPlan()) for t in (single, ora, mesh))
+    for k in range(900):
+        single.step(0.1, report=False)
+        mesh.step(0.1, report=report)
+        ora.step(0.1)
+    a, b, c = single.read_agents(), mesh.read_agents(), ora.read_agents()
+    assert len(a) > 100 and a.tobytes() == b.tobytes()
+    assert (a["id"] == c["id"]).all() and (a["next_waypoint"] == c["next_waypoint"]).all()
+    assert float(np.hypot(a["x"] - c["x"], a["y"] - c["y"]).max() / 160.0) <= 1e-4
+    key = lambda calls: [(round(s_[0], 3), round(s_[1], 3), g_) for s_, g_ in calls]  # noqa: E731
+    assert key(r_single.calls) == key(r_ora.calls) and len(r_single.calls) >= 32  # second legs were planned too
+    # every tile planned the same routes in the same order (its book numbers them like the others')
+    per_tile = len(r_mesh.calls) // len(mesh.engines)
+    assert per_tile * len(mesh.engines) == len(r_mesh.calls) and per_tile == len(r_single.calls)
+    assert (a["next_waypoint"] == 1).sum() > 20  # walkers on their second leg
+
+
+def test_route_planners_on_tiles_without_a_route():
+    """A sink whose first leg cannot be planned is refused at registration on a tile engine (the
+    route book must be the same on every tile before the first step); agents without a target
+    stand still, as on a single engine (rmf/mod.rs:211-214)."""
     from rmf_crowdsim_amd import CrowdSimError, MonotonicCrowd, RouteFollower, SourceSink
     mesh = LocalTileMesh(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)), (2, 1), halo_cells=1)
     hlp = RouteFollower(lambda s, g: [s, g] if g[0] < 900.0 else None)
-    with pytest.raises(CrowdSimError, match="one waypoint"):
-        mesh.add_source_sink(SourceSink((5.0, 5.0), 1.0, MonotonicCrowd(1.0), hlp, NoLocalPlan(),
-                                        [(20.0, 5.0), (30.0, 5.0)], False, 2.0))
     with pytest.raises(CrowdSimError, match="no route"):
         mesh.add_source_sink(SourceSink((5.0, 5.0), 1.0, MonotonicCrowd(1.0), hlp, NoLocalPlan(),
                                         [(950.0, 5.0)], False, 2.0))
-    # agents without a target stand still, as on a single engine (rmf/mod.rs:211-214)
     mesh.add_agents(np.array([[5.0, 5.0], [30.0, 30.0]]), hlp, NoLocalPlan(), 2.0)
     for _ in range(3):
         mesh.step(0.1)
