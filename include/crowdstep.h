@@ -278,6 +278,18 @@ size_t cs_query_radius(cs_engine*, double radius, double x, double y,
 /* SpatialIndex::get_nearest_neighbours                  location_hash_2d.rs:151-238 */
 size_t cs_query_knn(cs_engine*, size_t k, double x, double y, uint64_t* out_ids);
 
+/* Batch forms: n queries in one launch (one wave per query).  out_ids holds cap_per_query entries
+ * per query (query i at out_ids + i * cap_per_query, same order as cs_query_radius), out_counts[i]
+ * the full count of query i; out_d2 (squared distances, f32) and out_cells (the GLOBAL cell of each
+ * hit, x * (width / cell) + y) are optional (NULL).  On a TILE engine these calls are available and
+ * report the agents the tile OWNS; between steps every agent is owned by exactly one tile, so the
+ * union over the tiles of a mesh, ordered by (cell, id), is the reference's answer.
+ * cs_query_knn_batch: out_ids / out_d2 hold k entries per query, out_counts[i] <= k. */
+int cs_query_radius_batch(cs_engine*, size_t n, const double* xy, const double* radius, size_t cap_per_query,
+                          uint64_t* out_ids, uint64_t* out_counts, float* out_d2, uint32_t* out_cells);
+int cs_query_knn_batch(cs_engine*, size_t n, const double* xy, size_t k, uint64_t* out_ids, uint64_t* out_counts,
+                       float* out_d2);
+
 /* Device memory the engine holds, in bytes.  It grows with the agent CAPACITY (slots), the grid and
  * the number of source-sinks and routes, never with the number of steps or of ids handed out. */
 uint64_t cs_device_bytes(cs_engine*);

@@ -894,6 +894,27 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
 void cs_remove_source_sink(cs_engine* e, uint32_t handle) { e->source_sinks.erase(handle); }
 size_t cs_source_sink_slots(cs_engine* e) { return e->next_sink_handle; }
 uint64_t cs_device_bytes(cs_engine*) { return 0; }
+// batch forms: the single queries in a loop (location_hash_2d.rs:240-258, :151-238)
+size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap);
+size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_ids);
+int cs_query_radius_batch(cs_engine* e, size_t n, const double* xy, const double* radius, size_t cap_per_query,
+                          uint64_t* out_ids, uint64_t* out_counts, float*, uint32_t*) {
+  for (size_t i = 0; i < n; ++i) {
+    const size_t c = cs_query_radius(e, radius[i], xy[2 * i], xy[2 * i + 1], out_ids + i * cap_per_query, cap_per_query);
+    if (out_counts) out_counts[i] = c;
+  }
+  return 0;
+}
+int cs_query_knn_batch(cs_engine* e, size_t n, const double* xy, size_t k, uint64_t* out_ids, uint64_t* out_counts,
+                       float*) {
+  for (size_t i = 0; i < n; ++i) {
+    std::vector<uint64_t> tmp(k + e->agents.size() + 1);
+    const size_t c = std::min(k, cs_query_knn(e, k, xy[2 * i], xy[2 * i + 1], tmp.data()));
+    for (size_t j = 0; j < c; ++j) out_ids[i * k + j] = tmp[j];
+    if (out_counts) out_counts[i] = c;
+  }
+  return 0;
+}
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
   const int rc = e->step(dt_seconds, report);

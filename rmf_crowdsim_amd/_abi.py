@@ -138,6 +138,11 @@ SYMBOLS = {
                                      C.POINTER(C.c_uint64), C.c_size_t]),
     "cs_query_knn": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                   C.POINTER(C.c_uint64)]),
+    "cs_query_radius_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "cs_query_knn_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_size_t,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "cs_profile_enable": (None, [C.c_void_p, C.c_uint32]),
     "cs_profile_stride": (None, [C.c_void_p, C.c_uint32]),
     "cs_profile_read": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double),

@@ -473,6 +473,153 @@ static size_t radius_query(cs_engine* e, double radius, double x, double y, std:
   return cnt;
 }
 
+// The batch form of radius_query: n queries in one launch (k_query_radius_batch).  ids / d2 / cells
+// hold cap entries per query, counts the full count per query.  On a tile engine the query runs
+// against the local grid and reports owned agents only.
+static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const double* radius, size_t cap,
+                              std::vector<uint32_t>* ids, std::vector<float>* d2, std::vector<uint32_t>* cells,
+                              std::vector<uint32_t>* counts, bool every_alias) {
+  counts->assign(n, 0u);
+  ids->assign(n * cap, 0u);
+  d2->assign(n * cap, 0.0f);
+  cells->assign(n * cap, 0u);
+  if (n == 0 || cap == 0) return 0;
+  if (n > 0x7FFFFFFFull || n * cap > 0x7FFFFFFFull) {
+    e->error = "batch query too large";
+    return 3;
+  }
+  if (int rc = e->refresh_counts()) return rc;
+  if (int rc = e->ensure_index()) return rc;
+  std::vector<QueryDev> q(n);
+  const long long n_rows = (long long)(e->ncells / std::max<uint64_t>(e->nx, 1));
+  auto fl = [&](double v, double o) -> long long {
+    double f = std::floor((v - o) / e->grid.cell_size);
+    if (f != f) return 0;
+    if (f > 4e18) return (long long)4e18;
+    if (f < -4e18) return (long long)-4e18;
+    return (long long)f;
+  };
+  for (size_t k = 0; k < n; ++k) {
+    const double x = xy[2 * k], y = xy[2 * k + 1], r = radius[k];
+    // get_bounds (:103-122) in f64 on the global query point, then into the local grid of a tile
+    const long long ox = (long long)e->gdev.org_x, oy = (long long)e->gdev.org_y;
+    long long lx = fl(x - r, e->grid.offset_x) - ox, hx = fl(x + r, e->grid.offset_x) - ox;
+    long long ly = fl(y - r, e->grid.offset_y) - oy, hy = fl(y + r, e->grid.offset_y) - oy;
+    lx = std::max(lx, -1ll);
+    ly = std::max(ly, -1ll);
+    hx = std::min(hx, n_rows);
+    hy = std::min(hy, e->tile ? (long long)e->nx - 1 : (every_alias ? (long long)e->ncells : (long long)e->nx * 2));
+    // query point relative to a reference cell: the cell of the point clamped into the (local) grid
+    const long long qx = std::min(std::max(fl(x, e->grid.offset_x) - ox, 0ll), std::max(n_rows - 1, 0ll));
+    const long long qy = std::min(std::max(fl(y, e->grid.offset_y) - oy, 0ll), (long long)e->nx - 1);
+    QueryDev& Q = q[k];
+    Q.lx = lx; Q.hx = hx; Q.ly = ly; Q.hy = hy;
+    Q.qcx = (uint32_t)qx;
+    Q.qcy = (uint32_t)qy;
+    Q.qox = (float)((x - e->grid.offset_x) - (double)(qx + ox) * e->grid.cell_size);
+    Q.qoy = (float)((y - e->grid.offset_y) - (double)(qy + oy) * e->grid.cell_size);
+    Q.r = (float)r;
+    Q.pad = 0;
+  }
+  QueryDev* d_q = nullptr;
+  uint32_t *d_ids = nullptr, *d_cells = nullptr, *d_cnt = nullptr;
+  float* d_d2 = nullptr;
+  bool ok = hipMalloc(&d_q, n * sizeof(QueryDev)) == hipSuccess && hipMalloc(&d_ids, n * cap * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&d_d2, n * cap * sizeof(float)) == hipSuccess && hipMalloc(&d_cells, n * cap * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&d_cnt, n * sizeof(uint32_t)) == hipSuccess;
+  if (ok) {
+    ok = hipMemcpyAsync(d_q, q.data(), n * sizeof(QueryDev), hipMemcpyHostToDevice, e->stream) == hipSuccess;
+    hipLaunchKernelGGL(k_query_radius_batch, dim3((uint32_t)n), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
+                       e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, d_ids, d_d2, d_cells, (uint32_t)cap, d_cnt);
+    ok = ok && hipMemcpyAsync(counts->data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipMemcpyAsync(ids->data(), d_ids, n * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipMemcpyAsync(d2->data(), d_d2, n * cap * sizeof(float), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipMemcpyAsync(cells->data(), d_cells, n * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+         hipStreamSynchronize(e->stream) == hipSuccess;
+  }
+  hipFree(d_q); hipFree(d_ids); hipFree(d_d2); hipFree(d_cells); hipFree(d_cnt);
+  if (!ok) {
+    e->error = "HIP error in a batch of spatial queries";
+    return 90;
+  }
+  return 0;
+}
+
+int cs_query_radius_batch(cs_engine* e, size_t n, const double* xy, const double* radius, size_t cap_per_query,
+                          uint64_t* out_ids, uint64_t* out_counts, float* out_d2, uint32_t* out_cells) {
+  hipSetDevice(e->device);
+  std::vector<uint32_t> ids, cells, counts;
+  std::vector<float> d2;
+  if (int rc = radius_query_batch(e, n, xy, radius, cap_per_query, &ids, &d2, &cells, &counts, true)) return rc;
+  for (size_t k = 0; k < n; ++k) {
+    if (out_counts) out_counts[k] = counts[k];
+    const size_t m = std::min<size_t>(counts[k], cap_per_query);
+    for (size_t i = 0; i < m; ++i) {
+      out_ids[k * cap_per_query + i] = ids[k * cap_per_query + i];
+      if (out_d2) out_d2[k * cap_per_query + i] = d2[k * cap_per_query + i];
+      if (out_cells) out_cells[k * cap_per_query + i] = cells[k * cap_per_query + i];
+    }
+  }
+  return 0;
+}
+
+// k nearest agents of n points at once: batches of radius queries with a doubling radius for the
+// points that do not hold k agents yet, then the k smallest distances (ties by ascending id).
+int cs_query_knn_batch(cs_engine* e, size_t n, const double* xy, size_t k, uint64_t* out_ids, uint64_t* out_counts,
+                       float* out_d2) {
+  hipSetDevice(e->device);
+  for (size_t i = 0; i < n && out_counts; ++i) out_counts[i] = 0;
+  if (n == 0 || k == 0) return 0;
+  if (int rc = e->refresh_counts()) return rc;
+  const uint64_t population = e->n_alive_host;
+  std::vector<double> r(n, e->grid.cell_size), qxy, qr;
+  std::vector<size_t> todo(n), next;
+  for (size_t i = 0; i < n; ++i) todo[i] = i;
+  size_t cap = std::max<size_t>(2 * k + 16, 32);
+  while (!todo.empty()) {
+    qxy.resize(2 * todo.size());
+    qr.resize(todo.size());
+    for (size_t t = 0; t < todo.size(); ++t) {
+      qxy[2 * t] = xy[2 * todo[t]];
+      qxy[2 * t + 1] = xy[2 * todo[t] + 1];
+      qr[t] = r[todo[t]];
+    }
+    std::vector<uint32_t> ids, cells, counts;
+    std::vector<float> d2;
+    if (int rc = radius_query_batch(e, todo.size(), qxy.data(), qr.data(), cap, &ids, &d2, &cells, &counts, false)) return rc;
+    next.clear();
+    bool grow_cap = false;
+    for (size_t t = 0; t < todo.size(); ++t) {
+      const size_t i = todo[t];
+      const double reach = 2.0 * (std::fabs(xy[2 * i] - e->grid.offset_x) + std::fabs(xy[2 * i + 1] - e->grid.offset_y) +
+                                  e->grid.width + e->grid.height);
+      if (counts[t] > cap) {  // more in sight than the buffer holds: same radius, larger buffer
+        grow_cap = true;
+        next.push_back(i);
+        continue;
+      }
+      std::vector<std::pair<float, uint32_t>> by_dist(counts[t]);
+      for (size_t m = 0; m < counts[t]; ++m) by_dist[m] = {d2[t * cap + m], ids[t * cap + m]};
+      std::sort(by_dist.begin(), by_dist.end());
+      by_dist.erase(std::unique(by_dist.begin(), by_dist.end()), by_dist.end());  // aliased cells list a member twice
+      if (by_dist.size() < k && by_dist.size() < population && r[i] <= reach) {
+        r[i] *= 2.0;
+        next.push_back(i);
+        continue;
+      }
+      const size_t m = std::min(k, by_dist.size());
+      for (size_t j = 0; j < m; ++j) {
+        out_ids[i * k + j] = by_dist[j].second;
+        if (out_d2) out_d2[i * k + j] = by_dist[j].first;
+      }
+      if (out_counts) out_counts[i] = m;
+    }
+    if (grow_cap) cap *= 4;
+    todo.swap(next);
+  }
+  return 0;
+}
+
 // SpatialIndex::get_neighbours_in_radius, location_hash_2d.rs:240-258
 size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap) {
   hipSetDevice(e->device);

@@ -474,6 +474,50 @@ class Simulation:
                                      out.ctypes.data_as(C.POINTER(C.c_uint64)))
         return [int(i) for i in out[:got]]
 
+    def query_radius_batch(self, radii, positions, details=False):
+        """n radius queries in one launch (cs_query_radius_batch).  -> list of id lists in the order of
+        get_neighbours_in_radius; with details=True a list of (ids, squared distances, global cells)
+        arrays per query (what a tile mesh needs to merge the answers of its tiles)."""
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float64).reshape(-1, 2))
+        n = len(pos)
+        rad = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float64), (n,)))
+        cap = 64
+        while True:
+            ids = np.zeros((n, cap), dtype=np.uint64)
+            counts = np.zeros(n, dtype=np.uint64)
+            d2 = np.zeros((n, cap), dtype=np.float32)
+            cells = np.zeros((n, cap), dtype=np.uint32)
+            rc = self._lib.cs_query_radius_batch(
+                self._engine, n, pos.ctypes.data_as(C.POINTER(C.c_double)), rad.ctypes.data_as(C.POINTER(C.c_double)),
+                cap, ids.ctypes.data_as(C.POINTER(C.c_uint64)), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                d2.ctypes.data_as(C.POINTER(C.c_float)), cells.ctypes.data_as(C.POINTER(C.c_uint32)))
+            if rc != 0:
+                raise self._err()
+            if n == 0 or counts.max() <= cap:
+                break
+            cap = int(counts.max())
+        if details:
+            return [(ids[i, :int(counts[i])].copy(), d2[i, :int(counts[i])].copy(), cells[i, :int(counts[i])].copy())
+                    for i in range(n)]
+        return [[int(v) for v in ids[i, :int(counts[i])]] for i in range(n)]
+
+    def query_knn_batch(self, k, positions, details=False):
+        """The k nearest agents of n points in one call (cs_query_knn_batch), nearest first, ties by id."""
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float64).reshape(-1, 2))
+        n, k = len(pos), int(k)
+        ids = np.zeros((n, max(k, 1)), dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint64)
+        d2 = np.zeros((n, max(k, 1)), dtype=np.float32)
+        rc = self._lib.cs_query_knn_batch(self._engine, n, pos.ctypes.data_as(C.POINTER(C.c_double)), k,
+                                          ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          d2.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != 0:
+            raise self._err()
+        if details:
+            return [(ids[i, :int(counts[i])].copy(), d2[i, :int(counts[i])].copy()) for i in range(n)]
+        return [[int(v) for v in ids[i, :int(counts[i])]] for i in range(n)]
+
     # -- streaming view for renderers (lib.rs:71 read every frame, main.rs:112-128) --
     def request_snapshot(self):
         """Queue a copy of the live agents into pinned host memory behind the steps queued so

@@ -141,6 +141,24 @@ def _has_route_legs(source_sink):
     return isinstance(source_sink.high_level_planner, RouteFollower) and len(source_sink.waypoints) > 1
 
 
+def merge_radius_answers(parts):
+    """Answers of the tiles of a mesh to one radius query -> the reference's list: cells x-major /
+    y-minor (the global cell number is x * stride + y), ascending id inside a cell.  parts: (ids,
+    squared distances, global cells) per tile, each tile reporting the agents it owns."""
+    ids = np.concatenate([p[0] for p in parts])
+    cells = np.concatenate([p[2] for p in parts])
+    order = np.lexsort((ids, cells))
+    return [int(v) for v in ids[order]]
+
+
+def merge_knn_answers(parts, k):
+    """k nearest over the tiles: every tile's k nearest owned agents, merged by (distance, id)."""
+    ids = np.concatenate([p[0] for p in parts])
+    d2 = np.concatenate([p[1] for p in parts])
+    order = np.lexsort((ids, d2))[:k]
+    return [int(v) for v in ids[order]]
+
+
 class _TileBase:
     def _make_engine(self, spatial_index, layout, index, halo_cells, device, stream, capacity_hint,
                      flags):
@@ -286,6 +304,21 @@ class LocalTileMesh(_TileBase):
             if misses:
                 for sim in self.engines:
                     sim.route_resolve(misses)
+
+    # SpatialIndex on a mesh (spatial_index.rs:4-14): every tile answers for the agents it owns
+    def get_neighbours_in_radius_batch(self, radii, positions):
+        per_tile = [sim.query_radius_batch(radii, positions, details=True) for sim in self.engines]
+        return [merge_radius_answers([t[q] for t in per_tile]) for q in range(len(per_tile[0]))]
+
+    def get_neighbours_in_radius(self, radius, position):
+        return self.get_neighbours_in_radius_batch([radius], [position])[0]
+
+    def get_nearest_neighbours_batch(self, n, positions):
+        per_tile = [sim.query_knn_batch(n, positions, details=True) for sim in self.engines]
+        return [merge_knn_answers([t[q] for t in per_tile], int(n)) for q in range(len(per_tile[0]))]
+
+    def get_nearest_neighbours(self, n, position):
+        return self.get_nearest_neighbours_batch(n, [position])[0]
 
     def read_agents(self):
         parts = [sim.read_agents() for sim in self.engines]
@@ -497,6 +530,25 @@ class DistributedTiles(_TileBase):
                 parts = [None] * self.dist.get_world_size()
                 self.dist.all_gather_object(parts, mine)
                 self.sim.route_resolve(sorted(m for part in parts for m in part))
+
+    # SpatialIndex on a mesh, collective: every rank asks the same queries and gets the full answers
+    def get_neighbours_in_radius_batch(self, radii, positions):
+        mine = self.sim.query_radius_batch(radii, positions, details=True)
+        parts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(parts, mine)
+        return [merge_radius_answers([t[q] for t in parts]) for q in range(len(mine))]
+
+    def get_neighbours_in_radius(self, radius, position):
+        return self.get_neighbours_in_radius_batch([radius], [position])[0]
+
+    def get_nearest_neighbours_batch(self, n, positions):
+        mine = self.sim.query_knn_batch(n, positions, details=True)
+        parts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(parts, mine)
+        return [merge_knn_answers([t[q] for t in parts], int(n)) for q in range(len(mine))]
+
+    def get_nearest_neighbours(self, n, position):
+        return self.get_nearest_neighbours_batch(n, [position])[0]
 
     def _allreduce_max(self, t):
         """MAX over the ranks of a device tensor, on the engine's stream."""

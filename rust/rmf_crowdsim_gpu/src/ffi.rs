@@ -220,6 +220,8 @@ extern "C" {
     pub fn cs_snapshot_acquire(e: *mut cs_engine, wait: c_int, out: *mut *const cs_snapshot_record, n: *mut usize, step_index: *mut u64) -> c_int;
     pub fn cs_query_radius(e: *mut cs_engine, radius: f64, x: f64, y: f64, out_ids: *mut u64, cap: usize) -> usize;
     pub fn cs_query_knn(e: *mut cs_engine, k: usize, x: f64, y: f64, out_ids: *mut u64) -> usize;
+    pub fn cs_query_radius_batch(e: *mut cs_engine, n: usize, xy: *const f64, radius: *const f64, cap_per_query: usize, out_ids: *mut u64, out_counts: *mut u64, out_d2: *mut f32, out_cells: *mut u32) -> c_int;
+    pub fn cs_query_knn_batch(e: *mut cs_engine, n: usize, xy: *const f64, k: usize, out_ids: *mut u64, out_counts: *mut u64, out_d2: *mut f32) -> c_int;
     pub fn cs_profile_enable(e: *mut cs_engine, kernel_mask: u32);
     pub fn cs_profile_stride(e: *mut cs_engine, every: u32);
     pub fn cs_profile_read(e: *mut cs_engine, kernel: u32, total_ms: *mut f64, launches: *mut u64) -> c_int;

@@ -804,6 +804,36 @@ def test_a_long_stream_of_route_followers_holds_constant_device_memory():
     assert np.allclose(a["vx"], 1.3, rtol=1e-6) and np.isfinite(a["x"]).all()
 
 
+def test_batch_spatial_queries_match_the_oracle_and_the_single_queries():
+    """cs_query_radius_batch / cs_query_knn_batch (one wave per query) against the oracle's
+    get_neighbours_in_radius (location_hash_2d.rs:240-258: same ids in the same order) and against the
+    engine's own one-at-a-time queries; 400 random queries, some outside the grid, between steps."""
+    sim, ora = both(dict(width=80.0, height=80.0, cell_size=2.0, offset=(-10.0, -10.0)))
+    pts = scenes.jittered_lattice(6000, 0.63, (0.0, 0.0), 0.3, 17)
+    for s in (sim, ora):
+        s.add_agents(pts, IdParityHighLevelPlan((0.0, 0.4)), Zanlungo(0.05, 1.0, 0.0, 0.4, 2.0, 0.2), 2.0)
+        for _ in range(5):
+            s.step(0.05)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-14.0, 74.0, (400, 2))
+    radii = rng.choice([0.3, 1.0, 2.5, 7.0], 400)
+    got = sim.query_radius_batch(radii, q)
+    assert sum(len(g) for g in got) > 5000
+    for i in range(400):
+        assert got[i] == ora.get_neighbours_in_radius(radii[i], q[i]), i
+    for i in range(0, 400, 37):
+        assert got[i] == sim.get_neighbours_in_radius(radii[i], q[i])
+    knn = sim.query_knn_batch(5, q[:120])
+    a = ora.read_agents()
+    for i in range(120):
+        d = np.hypot(a["x"] - q[i, 0], a["y"] - q[i, 1])
+        want = [int(v) for v in a["id"][np.lexsort((a["id"], d))[:5]]]
+        # (ties between equally distant agents are broken by the f32 distance on the device)
+        assert knn[i] == want or np.allclose(np.sort(d)[:5], np.sort([d[a["id"] == v][0] for v in knn[i]]), rtol=1e-5), i
+        assert knn[i] == sim.get_nearest_neighbours(5, q[i]) or i % 13
+    assert sim.query_radius_batch([], np.zeros((0, 2))) == [] and sim.query_knn_batch(3, np.zeros((0, 2))) == []
+
+
 def test_three_way_parity_isolates_rounding_from_kernel_errors():
     """engine (f32, cell-relative) vs the oracle built in f32 (same algorithm,
     global f32 coordinates) vs the f64 oracle.  If the engine disagreed with the f64 oracle by

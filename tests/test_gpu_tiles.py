@@ -950,3 +950,32 @@ def test_route_planners_on_tiles_without_a_route():
         mesh.step(0.1)
     a = mesh.read_agents()
     assert np.allclose(a["x"], [5.0, 30.0]) and np.allclose(a["y"], [5.0, 30.0])
+
+
+@pytest.mark.parametrize("tiles", [(2, 2), (3, 1)])
+def test_spatial_queries_on_a_mesh_match_the_single_engine(tiles):
+    """SpatialIndex on a tile mesh (spatial_index.rs:4-14): every tile answers for the agents it owns
+    (cs_query_radius_batch / cs_query_knn_batch on a tile engine), the answers are merged by (cell,
+    id) / (distance, id).  Same lists as the single engine, for discs that straddle the cuts."""
+    n = 8000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=31, cell_size=2.0, margin=12.0)
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=1)
+    for t in (single, mesh):
+        scenes.add_walking_crowd(t, pts, group, Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)  # agents migrate across the cuts
+        for _ in range(12):
+            t.step(0.05, report=False)
+    rng = np.random.default_rng(8)
+    q = rng.uniform(8.0, 8.0 + extent + 8.0, (150, 2))
+    radii = rng.choice([0.5, 2.0, 6.0, 15.0], 150)
+    a = single.query_radius_batch(radii, q)
+    b = mesh.get_neighbours_in_radius_batch(radii, q)
+    assert a == b and sum(len(x) for x in a) > 3000
+    assert mesh.get_neighbours_in_radius(6.0, q[3]) == single.get_neighbours_in_radius(6.0, q[3])
+    assert mesh.get_nearest_neighbours_batch(7, q[:60]) == single.query_knn_batch(7, q[:60])
+    assert mesh.get_nearest_neighbours(3, q[0]) == single.get_nearest_neighbours(3, q[0])
+    # stepping goes on afterwards (the queries re-sorted the tiles' arrays)
+    for t in (single, mesh):
+        for _ in range(5):
+            t.step(0.05, report=False)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
