@@ -282,8 +282,9 @@ size_t cs_query_knn(cs_engine*, size_t k, double x, double y, uint64_t* out_ids)
  * per query (query i at out_ids + i * cap_per_query, same order as cs_query_radius), out_counts[i]
  * the full count of query i; out_d2 (squared distances, f32) and out_cells (the GLOBAL cell of each
  * hit, x * (width / cell) + y) are optional (NULL).  On a TILE engine these calls are available and
- * report the agents the tile OWNS; between steps every agent is owned by exactly one tile, so the
- * union over the tiles of a mesh, ordered by (cell, id), is the reference's answer.
+ * report the agents the tile HOLDS (after a step: everything it stepped, also what has just walked
+ * into its ring; after a halo exchange: what lies in its owned cells); every agent is held by exactly
+ * one tile, so the union over the tiles of a mesh, ordered by (cell, id), is the reference's answer.
  * cs_query_knn_batch: out_ids / out_d2 hold k entries per query, out_counts[i] <= k. */
 int cs_query_radius_batch(cs_engine*, size_t n, const double* xy, const double* radius, size_t cap_per_query,
                           uint64_t* out_ids, uint64_t* out_counts, float* out_d2, uint32_t* out_cells);
@@ -365,6 +366,20 @@ int cs_spawn_commit(cs_engine*, const uint8_t* flags, size_t n);
  * callback planners and per-step reports; the host-side pair above remains for those. */
 int cs_spawn_probe_dev(cs_engine*, double dt_seconds, int* flags_dev, size_t cap);
 int cs_spawn_commit_dev(cs_engine*, const int* flags_dev, size_t n);
+
+/* Re-cutting a running mesh (a clustered crowd drifts: BASELINE.json configs[4]).  Between two
+ * steps: cs_tile_histogram adds the agents the tile holds per global x-row (height / cell entries)
+ * and y-column (width / cell entries) into the caller's arrays (summed over the tiles they give the
+ * new cuts); cs_tile_export writes every agent the tile holds as a halo record (CS_HALO_RECORD_BYTES each,
+ * host memory) and returns their number (SIZE_MAX on error; call with cap 0 to size the buffer);
+ * cs_tile_retile gives the engine a new owned rectangle: it forgets its agents and ghosts and its
+ * halo buffers (set them again: the edges moved), keeps planners, groups, source-sinks, the id
+ * counter and the routes; cs_tile_import takes, from the exports of ALL tiles, the records whose
+ * cell the engine now owns.  The next halo exchange refills the ghost rings. */
+int cs_tile_histogram(cs_engine*, uint64_t* rows, uint64_t* cols);
+size_t cs_tile_export(cs_engine*, void* records, size_t cap_records);
+int cs_tile_retile(cs_engine*, uint32_t tile_cx0, uint32_t tile_cx1, uint32_t tile_cy0, uint32_t tile_cy1);
+int cs_tile_import(cs_engine*, const void* records, size_t n);
 
 /* Route followers (CS_HLP_ROUTE) on tiles.  Route numbers travel in halo records, so every tile's
  * route book must number routes alike.  Legs after the first start wherever an agent stands when it

@@ -1036,6 +1036,19 @@ int cs_spawn_commit_dev(cs_engine* e, const int*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_tile_histogram(cs_engine* e, uint64_t*, uint64_t*) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+size_t cs_tile_export(cs_engine*, void*, size_t) { return SIZE_MAX; }
+int cs_tile_retile(cs_engine* e, uint32_t, uint32_t, uint32_t, uint32_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
+int cs_tile_import(cs_engine* e, const void*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 size_t cs_route_misses(cs_engine*, cs_route_miss*, size_t) { return 0; }
 int cs_route_resolve(cs_engine* e, const cs_route_miss*, size_t) {
   e->error = "oracle has no tiles";

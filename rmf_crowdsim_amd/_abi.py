@@ -158,6 +158,10 @@ SYMBOLS = {
     "cs_spawn_commit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]),
     "cs_spawn_probe_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]),
     "cs_spawn_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cs_tile_histogram": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cs_tile_export": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cs_tile_retile": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "cs_tile_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cs_route_misses": (C.c_size_t, [C.c_void_p, C.POINTER(RouteMiss), C.c_size_t]),
     "cs_route_resolve": (C.c_int, [C.c_void_p, C.POINTER(RouteMiss), C.c_size_t]),
     "cs_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

@@ -111,44 +111,10 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (gnc >= 0x7FFFFFFFull || e->gnx >= 0x7FFFFFFFull)
     return create_failed(e, "grid too large for 32-bit cell indices (" + std::to_string(e->gnx) + " x " +
                                 std::to_string(e->gny) + " cells)");
-  e->nx = e->gnx;
-  e->ny = e->gny;
   std::memset(&e->gdev, 0, sizeof e->gdev);
-  uint32_t ox0 = 0, ox1 = (uint32_t)e->gny, oy0 = 0, oy1 = (uint32_t)e->gnx, org_x = 0, org_y = 0;
-  if (cfg && (cfg->tile_cx1 | cfg->tile_cy1)) {
-    const uint32_t H = cfg->halo_cells;
-    if (cfg->tile_cx0 >= cfg->tile_cx1 || cfg->tile_cy0 >= cfg->tile_cy1 || cfg->tile_cx1 > e->gny ||
-        cfg->tile_cy1 > e->gnx || H == 0)
-      return create_failed(e, "bad tile rectangle / halo_cells");
-    e->tile = true;
-    e->halo_cells = H;
-    const uint32_t lx0 = cfg->tile_cx0 > H ? cfg->tile_cx0 - H : 0;
-    const uint32_t ly0 = cfg->tile_cy0 > H ? cfg->tile_cy0 - H : 0;
-    const uint32_t lx1 = (uint32_t)std::min<uint64_t>(e->gny, (uint64_t)cfg->tile_cx1 + H);
-    const uint32_t ly1 = (uint32_t)std::min<uint64_t>(e->gnx, (uint64_t)cfg->tile_cy1 + H);
-    e->ny = lx1 - lx0;
-    e->nx = ly1 - ly0;
-    org_x = lx0;
-    org_y = ly0;
-    ox0 = cfg->tile_cx0 - lx0;
-    ox1 = cfg->tile_cx1 - lx0;
-    oy0 = cfg->tile_cy0 - ly0;
-    oy1 = cfg->tile_cy1 - ly0;
-  }
-  e->ncells = e->nx * e->ny;
-  e->gdev.nx = (uint32_t)e->nx;
-  e->gdev.ny = (uint32_t)e->ny;
-  e->gdev.ncells = (uint32_t)e->ncells;
   e->gdev.cs = (float)grid->cell_size;
   e->gdev.cs_lo = (float)(grid->cell_size - (double)e->gdev.cs);
   e->gdev.inv_cs = 1.0f / e->gdev.cs;
-  e->gdev.tile = e->tile ? 1u : 0u;
-  e->gdev.own_x0 = ox0;
-  e->gdev.own_x1 = ox1;
-  e->gdev.own_y0 = oy0;
-  e->gdev.own_y1 = oy1;
-  e->gdev.org_x = org_x;
-  e->gdev.org_y = org_y;
   {  // fixed-point unit of the neighbour pass (fix_rel): the cell size is at most 2^23 units, i.e.
      // 2^-22 m for cells of (1, 2] m (two f32 spacings of an offset in the upper half of the
      // cell), so that a window of up to ~120 columns fits 2^30 units (tile_max_cols)
@@ -187,19 +153,14 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
+  const bool is_tile = cfg && (cfg->tile_cx1 | cfg->tile_cy1);
+  if (e->set_geometry(is_tile, is_tile ? cfg->tile_cx0 : 0, is_tile ? cfg->tile_cx1 : 0, is_tile ? cfg->tile_cy0 : 0,
+                      is_tile ? cfg->tile_cy1 : 0, is_tile ? cfg->halo_cells : 0) != 0)
+    return create_failed(e, e->error);
   bool ok = true;
-  ok = ok && hipMalloc(&e->cell_count, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
-  ok = ok && hipMalloc(&e->cell_start, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
-  e->n_scan_blocks = (uint32_t)std::max<uint64_t>(1, (e->ncells + SCAN_TILE - 1) / SCAN_TILE);
-  ok = ok && hipMalloc(&e->block_totals, e->n_scan_blocks * sizeof(uint32_t)) == hipSuccess;
-  ok = ok && hipMalloc(&e->band_prefix, (e->ncells + 1) * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&e->ctr, sizeof(Counters)) == hipSuccess;
   ok = ok && hipHostMalloc(&e->ctr_host, sizeof(Counters)) == hipSuccess;
-  if (ok) {
-    hipMemset(e->cell_count, 0, (e->ncells + 1) * sizeof(uint32_t));
-    hipMemset(e->cell_start, 0, (e->ncells + 1) * sizeof(uint32_t));
-    hipMemset(e->ctr, 0, sizeof(Counters));
-  }
+  if (ok) hipMemset(e->ctr, 0, sizeof(Counters));
   if (!ok || e->upload_sinks() != 0 ||
       e->reserve(cfg && cfg->capacity_hint ? cfg->capacity_hint : 1024) != 0) {
     return create_failed(e, "device allocation failed: " + e->error);
@@ -530,7 +491,8 @@ static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const do
   if (ok) {
     ok = hipMemcpyAsync(d_q, q.data(), n * sizeof(QueryDev), hipMemcpyHostToDevice, e->stream) == hipSuccess;
     hipLaunchKernelGGL(k_query_radius_batch, dim3((uint32_t)n), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
-                       e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, d_ids, d_d2, d_cells, (uint32_t)cap, d_cnt);
+                       e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, (e->tile && e->ghosts_present) ? 1u : 0u, d_ids,
+                       d_d2, d_cells, (uint32_t)cap, d_cnt);
     ok = ok && hipMemcpyAsync(counts->data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
          hipMemcpyAsync(ids->data(), d_ids, n * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
          hipMemcpyAsync(d2->data(), d_d2, n * cap * sizeof(float), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
@@ -780,6 +742,25 @@ int cs_halo_unpack(cs_engine* e, uint32_t axis) {
     return 3;
   }
   return e->halo_unpack(axis);
+}
+
+// ---- re-cutting a running mesh ----
+int cs_tile_histogram(cs_engine* e, uint64_t* rows, uint64_t* cols) {
+  hipSetDevice(e->device);
+  return e->tile_histogram(rows, cols);
+}
+size_t cs_tile_export(cs_engine* e, void* records, size_t cap_records) {
+  hipSetDevice(e->device);
+  const long long n = e->tile_export(static_cast<HaloRecord*>(records), cap_records);
+  return n < 0 ? SIZE_MAX : (size_t)n;
+}
+int cs_tile_retile(cs_engine* e, uint32_t cx0, uint32_t cx1, uint32_t cy0, uint32_t cy1) {
+  hipSetDevice(e->device);
+  return e->tile_retile(cx0, cx1, cy0, cy1);
+}
+int cs_tile_import(cs_engine* e, const void* records, size_t n) {
+  hipSetDevice(e->device);
+  return e->tile_import(static_cast<const HaloRecord*>(records), n);
 }
 
 // ---- route followers on tiles: keeping every tile's route book alike ----

@@ -580,6 +580,35 @@ class Simulation:
         if self._lib.cs_halo_unpack_all(self._engine) != 0:
             raise self._err()
 
+    # -- tiles: re-cutting a running mesh (cs_tile_histogram / _export / _retile / _import) --
+    def tile_histogram(self, rows, cols):
+        """Adds this tile's owned agents per global x-row / y-column into the uint64 arrays."""
+        if self._lib.cs_tile_histogram(self._engine, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       cols.ctypes.data_as(C.POINTER(C.c_uint64))) != 0:
+            raise self._err()
+
+    def tile_export(self):
+        """Every owned agent as a halo record: a (n, CS_HALO_RECORD_BYTES) uint8 array."""
+        n = self._lib.cs_tile_export(self._engine, None, 0)
+        if n == C.c_size_t(-1).value:
+            raise self._err()
+        buf = np.zeros((max(n, 1), _abi.CS_HALO_RECORD_BYTES), dtype=np.uint8)
+        got = self._lib.cs_tile_export(self._engine, buf.ctypes.data_as(C.c_void_p), n)
+        if got == C.c_size_t(-1).value:
+            raise self._err()
+        return buf[:min(n, got)]
+
+    def tile_retile(self, rect):
+        if self._lib.cs_tile_retile(self._engine, *[int(v) for v in rect]) != 0:
+            raise self._err()
+        self._agents_cache = None
+
+    def tile_import(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.uint8)
+        if len(rec) and self._lib.cs_tile_import(self._engine, rec.ctypes.data_as(C.c_void_p), len(rec)) != 0:
+            raise self._err()
+        self._agents_cache = None
+
     # -- tiles: route followers' set_target calls that missed the route book (cs_route_misses / _resolve) --
     def route_misses(self):
         n = self._lib.cs_route_misses(self._engine, None, 0)

@@ -59,11 +59,14 @@ class TileLayout:
     the quantiles of the per-row and per-column agent histograms, so a clustered crowd
     (BASELINE.json configs[4]) is spread more evenly; runs stay at least `min_cells` wide."""
 
-    def __init__(self, spatial_index, tiles_x, tiles_y, weights=None, min_cells=2):
+    def __init__(self, spatial_index, tiles_x, tiles_y, weights=None, min_cells=2, histograms=None):
         self.cols = int(spatial_index.width / spatial_index.cell_size)   # stride, y cells per row
         self.rows = int(spatial_index.height / spatial_index.cell_size)  # x rows
         self.tiles_x, self.tiles_y = int(tiles_x), int(tiles_y)
-        if weights is None:
+        if histograms is not None:  # (agents per x-row, agents per y-column): cs_tile_histogram over a mesh
+            self.x_edges = _weighted_edges(np.asarray(histograms[0], dtype=np.float64), self.tiles_x, int(min_cells))
+            self.y_edges = _weighted_edges(np.asarray(histograms[1], dtype=np.float64), self.tiles_y, int(min_cells))
+        elif weights is None:
             self.x_edges = [round(k * self.rows / self.tiles_x) for k in range(self.tiles_x + 1)]
             self.y_edges = [round(k * self.cols / self.tiles_y) for k in range(self.tiles_y + 1)]
         else:
@@ -189,22 +192,54 @@ class LocalTileMesh(_TileBase):
         # which the engine reads as "create your own", and then nothing orders pack -> copy -> unpack
         self.stream = torch.cuda.Stream(dev)
         stream = self.stream.cuda_stream
+        self.spatial_index = spatial_index
+        self._capacity_records, self._density_per_cell = capacity_records, density_per_cell
         self.engines, self.bufs = [], []
         for index in range(self.layout.n_tiles):
             sim = self._make_engine(spatial_index, self.layout, index, halo_cells, device, stream,
                                     capacity_hint, flags)
-            tx, ty = self.layout.coords(index)
-            cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
-            bufs = {}
-            for d in (EDGES if self.phases == 2 else ALL_DIRS):
-                if self.layout.neighbour(tx, ty, d) is None:
-                    continue
-                send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
-                sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
-                bufs[d] = (send, recv)
             self.engines.append(sim)
-            self.bufs.append(bufs)
+            self.bufs.append(self._set_buffers(sim, index))
         torch.cuda.synchronize(dev)  # the zero fills ran on the default stream
+
+    def _set_buffers(self, sim, index):
+        """Send / receive buffers of one tile towards its neighbours, sized for the current layout."""
+        tx, ty = self.layout.coords(index)
+        cap = self._capacity_records or halo_capacity(self.layout, self._density_per_cell, self.halo_cells)
+        bufs = {}
+        for d in (EDGES if self.phases == 2 else ALL_DIRS):
+            if self.layout.neighbour(tx, ty, d) is None:
+                continue
+            send, recv = self._alloc(self.torch, cap, self.bufs_device), self._alloc(self.torch, cap, self.bufs_device)
+            sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
+            bufs[d] = (send, recv)
+        return bufs
+
+    def tile_counts(self):
+        """Agents owned by each tile right now (tiles_x x tiles_y)."""
+        return np.array([len(sim) for sim in self.engines]).reshape(self.layout.tiles_x, self.layout.tiles_y)
+
+    def recut(self):
+        """Move the cuts to the quantiles of where the crowd stands NOW (a clustered crowd drifts,
+        BASELINE.json configs[4]): per-row / per-column agent histograms from the devices, a new
+        tensor-product layout, every agent handed to the tile that owns its cell from now on.
+        Between two steps; the state, and so every later step, is unchanged bit for bit."""
+        rows = np.zeros(self.layout.rows, dtype=np.uint64)
+        cols = np.zeros(self.layout.cols, dtype=np.uint64)
+        for sim in self.engines:
+            sim.tile_histogram(rows, cols)
+        self.layout = TileLayout(self.spatial_index, self.layout.tiles_x, self.layout.tiles_y,
+                                 min_cells=2 * self.halo_cells, histograms=(rows, cols))
+        exports = [sim.tile_export() for sim in self.engines]
+        self.torch.cuda.synchronize(self.bufs_device)
+        for index, sim in enumerate(self.engines):
+            sim.tile_retile(self.layout.rect(*self.layout.coords(index)))
+            self.bufs[index] = self._set_buffers(sim, index)
+        self.torch.cuda.synchronize(self.bufs_device)
+        for sim in self.engines:
+            for rec in exports:
+                sim.tile_import(rec)
+        return self.tile_counts()
 
     def add_agents(self, positions, high_level_planner, local_planner, eyesight):
         ids = None
@@ -417,14 +452,9 @@ class DistributedTiles(_TileBase):
         self.sim = self._make_engine(spatial_index, self.layout, self.index, halo_cells, device, stream,
                                      capacity_hint, flags)
         tx, ty = self.layout.coords(self.index)
-        cap = capacity_records or halo_capacity(self.layout, density_per_cell, halo_cells)
-        self.bufs = {}
-        for d in (EDGES if self.phases == 2 else ALL_DIRS):
-            if self.layout.neighbour(tx, ty, d) is None:
-                continue
-            send, recv = self._alloc(torch, cap, dev), self._alloc(torch, cap, dev)
-            self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
-            self.bufs[d] = (send, recv)
+        self.spatial_index, self.halo_cells, self.bufs_device = spatial_index, int(halo_cells), dev
+        self._capacity_records, self._density_per_cell = capacity_records, density_per_cell
+        self.bufs = self._set_buffers()
         self._op_cache = {} if dist.get_backend() == "nccl" else None
         if transport is None:
             transport = os.environ.get("CS_TILES_TRANSPORT", "engine" if dist.get_backend() == "nccl" else "torch")
@@ -438,6 +468,45 @@ class DistributedTiles(_TileBase):
             peers = [self.layout.neighbour(tx, ty, d) for d in ALL_DIRS]
             self.sim.halo_set_peers([-1 if (p is None or d not in self.bufs) else p for p, d in zip(peers, ALL_DIRS)])
         torch.cuda.synchronize(dev)
+
+    def _set_buffers(self):
+        tx, ty = self.layout.coords(self.index)
+        cap = self._capacity_records or halo_capacity(self.layout, self._density_per_cell, self.halo_cells)
+        bufs = {}
+        for d in (EDGES if self.phases == 2 else ALL_DIRS):
+            if self.layout.neighbour(tx, ty, d) is None:
+                continue
+            send, recv = self._alloc(self.torch, cap, self.bufs_device), self._alloc(self.torch, cap, self.bufs_device)
+            self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
+            bufs[d] = (send, recv)
+        return bufs
+
+    def recut(self):
+        """Collective: new cuts at the quantiles of where the crowd stands now (LocalTileMesh.recut).
+        The histograms are summed over the ranks, the exported agents gathered on every rank (host
+        staged: a re-cut is rare), every rank keeps what its new rectangle owns."""
+        rows = np.zeros(self.layout.rows, dtype=np.uint64)
+        cols = np.zeros(self.layout.cols, dtype=np.uint64)
+        self.sim.tile_histogram(rows, cols)
+        both = self.torch.from_numpy(np.concatenate([rows, cols]).astype(np.int64))
+        if self.dist.get_backend() == "nccl":
+            both = both.to(self.bufs_device)
+        self.dist.all_reduce(both)
+        both = both.cpu().numpy()
+        self.layout = TileLayout(self.spatial_index, self.layout.tiles_x, self.layout.tiles_y,
+                                 min_cells=2 * self.halo_cells, histograms=(both[:len(rows)], both[len(rows):]))
+        parts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(parts, self.sim.tile_export())
+        self.torch.cuda.synchronize(self.bufs_device)
+        self.sim.tile_retile(self.layout.rect(*self.layout.coords(self.index)))
+        self.bufs = self._set_buffers()
+        self._op_cache = {} if self._op_cache is not None else None  # the P2P ops held the old buffers
+        self.torch.cuda.synchronize(self.bufs_device)
+        for rec in parts:
+            self.sim.tile_import(rec)
+        counts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(counts, len(self.sim))
+        return np.array(counts).reshape(self.layout.tiles_x, self.layout.tiles_y)
 
     def add_agents(self, positions, high_level_planner, local_planner, eyesight):
         return self.sim.add_agents(positions, high_level_planner, local_planner, eyesight)

@@ -235,6 +235,10 @@ extern "C" {
     pub fn cs_spawn_commit(e: *mut cs_engine, flags: *const u8, n: usize) -> c_int;
     pub fn cs_spawn_probe_dev(e: *mut cs_engine, dt_seconds: f64, flags_dev: *mut c_int, cap: usize) -> c_int;
     pub fn cs_spawn_commit_dev(e: *mut cs_engine, flags_dev: *const c_int, n: usize) -> c_int;
+    pub fn cs_tile_histogram(e: *mut cs_engine, rows: *mut u64, cols: *mut u64) -> c_int;
+    pub fn cs_tile_export(e: *mut cs_engine, records: *mut c_void, cap_records: usize) -> usize;
+    pub fn cs_tile_retile(e: *mut cs_engine, tile_cx0: u32, tile_cx1: u32, tile_cy0: u32, tile_cy1: u32) -> c_int;
+    pub fn cs_tile_import(e: *mut cs_engine, records: *const c_void, n: usize) -> c_int;
     pub fn cs_route_misses(e: *mut cs_engine, out: *mut cs_route_miss, cap: usize) -> usize;
     pub fn cs_route_resolve(e: *mut cs_engine, all: *const cs_route_miss, n: usize) -> c_int;
     pub fn cs_rccl_unique_id(out_id: *mut u8) -> c_int;

@@ -292,6 +292,8 @@ def _rank_sinks(rank, world, port, out_path, kind, layout):
         for k in range(400):
             if k == 120 and kind == "sinks":  # a removed sink keeps its slot: flags stay one per slot
                 tiles.remove_source_sink(3)
+            if k == 260 and kind in ("sinks", "legs"):  # collective re-cut of the running mesh
+                tiles.recut()
             tiles.step(dt, report=(k in (150, 151)))  # mostly the device-side spawn path
             if k == 200:  # a collective removal: the youngest walker, whichever rank holds it
                 ids = [None] * world
@@ -979,3 +981,45 @@ def test_spatial_queries_on_a_mesh_match_the_single_engine(tiles):
         for _ in range(5):
             t.step(0.05, report=False)
     assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+
+
+def test_recut_of_a_running_hotspot_crowd():
+    """BASELINE.json configs[4] in miniature, re-cut while running: hotspots on the low-x side of the
+    grid make even 4 x 2 cuts lopsided; LocalTileMesh.recut() moves the cuts to the quantiles of the
+    devices' row / column histograms and hands every agent to its new owner.  The mesh equals the
+    single engine bit for bit before and after the re-cut (and after walking on: the crowd walks
+    +x, so a second re-cut follows it), and the imbalance drops from 1.85 to 1.15."""
+    from rmf_crowdsim_amd import _abi
+    n = 120000
+    pts, grid, extent, group = scenes.hotspot_crowd(n, seed=11, cell_size=2.0, margin=10.0)
+    grid = dict(grid, width=grid["width"] + 60.0, height=grid["height"] + 60.0)  # room to walk: the crowd stands in a corner
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    single = Simulation(LocationHash2D(**grid), flags=_abi.CS_CFG_DENSE)
+    mesh = LocalTileMesh(LocationHash2D(**grid), (4, 2), halo_cells=1, density_per_cell=60.0, flags=_abi.CS_CFG_DENSE)
+    for t in (single, mesh):
+        scenes.add_walking_crowd(t, pts, group, lp, 2.0, creep=scenes.CREEP_SPEED * 0.1)
+
+    def both_step(k):
+        for _ in range(k):
+            single.step(0.05, report=False)
+            mesh.step(0.05, report=False)
+
+    both_step(5)
+    before = mesh.tile_counts()
+    assert before.max() / before.mean() > 1.25  # even cuts do not suit this crowd
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+    after = mesh.recut()
+    print(f"recut: {before.reshape(-1).tolist()} -> {after.reshape(-1).tolist()}")
+    # (cuts are a tensor product, so that every tile keeps its eight neighbours: row and column quantiles
+    # cannot level a lumpy 2-D density completely; the 4M crowd of configs[4] reaches 1.02)
+    assert after.sum() == n and after.max() / after.mean() <= 1.2
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+    both_step(200)  # 13 m further on: agents migrate over the new cuts, sinks / ghosts refill
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+    drifted = mesh.tile_counts()
+    again = mesh.recut()
+    both_step(10)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+    print(f"recut: max/mean {before.max() / before.mean():.2f} -> {after.max() / after.mean():.3f}; after 200 steps "
+          f"{drifted.max() / drifted.mean():.3f} -> {again.max() / again.mean():.3f}")
+    assert again.max() / again.mean() <= 1.2
