@@ -462,11 +462,30 @@ class DistributedTiles(_TileBase):
         if transport == "engine":
             # one RCCL communicator per engine: rank 0's unique id reaches the others through the
             # process group that already exists; from then on the halo traffic needs no torch
-            box = [self.sim.rccl_unique_id() if self.index == 0 else None]
+            failure = None
+            try:
+                box = [self.sim.rccl_unique_id() if self.index == 0 else None]
+            except Exception as err:  # librccl could not be bound on rank 0
+                box, failure = [None], err
             dist.broadcast_object_list(box, src=0)
-            self.sim.rccl_comm_init(dist.get_world_size(), self.index, box[0])
-            peers = [self.layout.neighbour(tx, ty, d) for d in ALL_DIRS]
-            self.sim.halo_set_peers([-1 if (p is None or d not in self.bufs) else p for p, d in zip(peers, ALL_DIRS)])
+            if box[0] is not None:
+                try:
+                    self.sim.rccl_comm_init(dist.get_world_size(), self.index, box[0])
+                    peers = [self.layout.neighbour(tx, ty, d) for d in ALL_DIRS]
+                    self.sim.halo_set_peers([-1 if (p is None or d not in self.bufs) else p
+                                             for p, d in zip(peers, ALL_DIRS)])
+                except Exception as err:
+                    failure = err
+            # every rank must use the same transport: if the engine's failed anywhere, all fall back
+            bad = torch.tensor([1 if (failure is not None or box[0] is None) else 0], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                bad = bad.to(dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                import sys
+                print(f"crowdstep: the engine's RCCL transport is not available ({failure}); using torch.distributed",
+                      file=sys.stderr)
+                self.transport = "torch"
         torch.cuda.synchronize(dev)
 
     def _set_buffers(self):

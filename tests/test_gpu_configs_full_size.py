@@ -67,6 +67,44 @@ def test_config1_exact_size():
     assert e_gpu_64 <= max(e_32_64, 1e-7) * 1.5
 
 
+def test_config1_full_size_for_the_north_star_s_1000_steps():
+    """The north star's parity clause at configs[1]'s size: 100,000 agents on 200 x 200 m, dt 0.05 s,
+    1000 steps, positions within 1e-4 (relative to the extent) of the CPU reference path.  The f64
+    side is the oracle's arithmetic on cell-sorted arrays spread over the host's cores
+    (oracle_fast_steps: bit-identical to the reference-shaped oracle, tests/test_oracle_reference_kats.py;
+    the reference-shaped one would take four minutes).  The reference's f64 path loses about one agent
+    per 1e6 agent-steps to its underflow flaw: those are left out, the engine must
+    stay finite."""
+    import os
+    from oracle_sim import fast_steps
+    n, steps = 100_000, 1000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    sim = Simulation(LocationHash2D(**grid))
+    ids = scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    for k in range(steps - 1):
+        sim.step(0.05, report=False)
+    sim.step(0.05)
+    assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0
+    a = sim.read_agents()
+    # the same crowd for the CPU side, in id order (ids follow add_counterflow: group 0 first)
+    by_id = np.empty_like(pts)
+    by_id[ids] = pts
+    pref = np.zeros_like(pts)
+    pref[ids, 1] = np.where(group == 0, scenes.CREEP_SPEED, -scenes.CREEP_SPEED)
+    xy, vel, sec = fast_steps(by_id, pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, steps,
+                              threads=min(16, os.cpu_count() or 1))
+    assert sec > 0
+    ok = np.isfinite(xy).all(axis=1)
+    assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all() and (~ok).sum() <= n // 200
+    dp = np.hypot(a["x"] - xy[:, 0], a["y"] - xy[:, 1])[ok]
+    force = np.hypot(vel[ok, 0], np.abs(vel[ok, 1]) - scenes.CREEP_SPEED)
+    print(f"configs[1], 1000 steps: |dp|/L = {dp.max() / extent:.2e} (p99.9 {np.quantile(dp, 0.999) / extent:.2e}); "
+          f"{int((~ok).sum())} agents NaN on the reference's f64 path; forced {float(np.mean(force > 0)):.3f}; "
+          f"CPU side {sec:.1f} s")
+    assert dp.max() / extent <= 1e-4 and np.mean(force > 0) > 0.9
+
+
 def _stream(target, lanes, lp, eyesight):
     plans = {}
     for src, dst, vel in lanes:
