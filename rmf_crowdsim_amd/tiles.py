@@ -130,6 +130,23 @@ def halo_capacity(layout, density_per_cell, halo_cells, slack=2.0):
     return int(max(1024, slack * density_per_cell * edge * 2 * halo_cells))
 
 
+def halo_capacity_of(layout, tx, ty, direction, density_per_cell, halo_cells, slack=2.0):
+    """Records of ONE direction's buffers; both ends of a link compute the same number (the cuts are a
+    tensor product: the tiles on either side of an edge have the same extent along it).  An edge
+    carries a band of 2 * halo cells along the shared edge, a corner the (2 * halo)^2 cells where two
+    bands cross: at 1M agents per tile the four corner buffers are a few KB instead of a megabyte
+    each, and the whole exchange a third of what one capacity for all eight directions made it."""
+    x0, x1, y0, y1 = layout.rect(tx, ty)
+    band = 2 * halo_cells
+    if direction in (XLO, XHI):
+        cells = (y1 - y0 + 4 * halo_cells) * band
+    elif direction in (YLO, YHI):
+        cells = (x1 - x0 + 4 * halo_cells) * band
+    else:
+        cells = 4 * band * band
+    return int(max(256, slack * density_per_cell * cells))
+
+
 def _is_data_planner(source_sink):
     """True when the sink's high-level planner runs on the device without host events.  A route
     follower on a tile qualifies: its routes are planned when the sink is registered."""
@@ -205,11 +222,13 @@ class LocalTileMesh(_TileBase):
     def _set_buffers(self, sim, index):
         """Send / receive buffers of one tile towards its neighbours, sized for the current layout."""
         tx, ty = self.layout.coords(index)
-        cap = self._capacity_records or halo_capacity(self.layout, self._density_per_cell, self.halo_cells)
         bufs = {}
         for d in (EDGES if self.phases == 2 else ALL_DIRS):
             if self.layout.neighbour(tx, ty, d) is None:
                 continue
+            cap = self._capacity_records or (
+                halo_capacity(self.layout, self._density_per_cell, self.halo_cells) if self.phases == 2 else
+                halo_capacity_of(self.layout, tx, ty, d, self._density_per_cell, self.halo_cells))
             send, recv = self._alloc(self.torch, cap, self.bufs_device), self._alloc(self.torch, cap, self.bufs_device)
             sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
             bufs[d] = (send, recv)
@@ -490,11 +509,13 @@ class DistributedTiles(_TileBase):
 
     def _set_buffers(self):
         tx, ty = self.layout.coords(self.index)
-        cap = self._capacity_records or halo_capacity(self.layout, self._density_per_cell, self.halo_cells)
         bufs = {}
         for d in (EDGES if self.phases == 2 else ALL_DIRS):
             if self.layout.neighbour(tx, ty, d) is None:
                 continue
+            cap = self._capacity_records or (
+                halo_capacity(self.layout, self._density_per_cell, self.halo_cells) if self.phases == 2 else
+                halo_capacity_of(self.layout, tx, ty, d, self._density_per_cell, self.halo_cells))
             send, recv = self._alloc(self.torch, cap, self.bufs_device), self._alloc(self.torch, cap, self.bufs_device)
             self.sim.halo_set_buffers(d, send.data_ptr(), recv.data_ptr(), cap)
             bufs[d] = (send, recv)
