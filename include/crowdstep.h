@@ -420,6 +420,11 @@ int cs_halo_exchange_rccl(cs_engine*, int32_t axis);
 /* max over the ranks, element by element, in place (the OR of the spawn flags of
  * cs_spawn_probe_dev), on the engine's stream */
 int cs_allreduce_max_i32_rccl(cs_engine*, int* values_dev, size_t n);
+/* One multi-GPU step of a tile in one call: cs_halo_pack_all -> cs_halo_exchange_rccl(-1) ->
+ * cs_halo_unpack_all -> (with source-sinks: cs_spawn_probe_dev -> cs_allreduce_max_i32_rccl ->
+ * cs_spawn_commit_dev on flags the engine keeps) -> cs_step, all on the engine's stream.  For hosts
+ * without listeners, host planners or multi-leg route sinks (they use the split calls). */
+int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
 
 #ifdef __cplusplus
 }

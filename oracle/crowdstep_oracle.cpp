@@ -1075,6 +1075,10 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_tile_step_rccl(cs_engine* e, double, cs_step_report*) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 
 // Oracle-only probes used by tests/test_oracle_reference_kats.py to pin the
 // private pieces the reference's own unit tests reach (zanlungo.rs:225-236).

@@ -45,6 +45,15 @@
 #include "cs_engine.hip.inc"
 #include "cs_rccl.hip.inc"
 
+#define HIP_OK_E(e, call)                                                                     \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (e)->error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call;         \
+      return 90;                                                                              \
+    }                                                                                         \
+  } while (0)
+
 // ===========================================================================
 // C ABI (include/crowdstep.h)
 // ===========================================================================
@@ -71,7 +80,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -878,6 +887,43 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int* values_dev, size_t n) {
   if (n == 0) return 0;
   return rccl_api::ok(e, a.all_reduce(values_dev, values_dev, n, rccl_api::kInt32, rccl_api::kMax, e->rccl_comm, e->stream),
                       "ncclAllReduce") ? 0 : 8;
+}
+
+// The whole multi-GPU step of a tile in ONE call, on the engine's stream, nothing waiting for the
+// host: halo pack -> RCCL exchange -> unpack -> (source-sinks: device-side probe, all-reduce of the
+// flags, commit) -> cs_step.  For hosts without listeners, host planners or multi-leg route sinks
+// (those need the split calls: events must reach the host between the phases).
+int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
+  hipSetDevice(e->device);
+  if (!e->tile) {
+    e->error = "cs_tile_step_rccl needs a tile engine";
+    return 3;
+  }
+  if (int rc = e->halo_pack_all()) return rc;
+  if (int rc = cs_halo_exchange_rccl(e, -1)) return rc;
+  if (int rc = e->halo_unpack_all()) return rc;
+  if (int rc = e->upload_sinks()) return rc;
+  if (int rc = e->upload_groups()) return rc;
+  if (e->n_live_sinks > 0) {
+    if (e->record_events || e->any_callback_hlp) {
+      e->error = "cs_tile_step_rccl: listeners and host planners need the split calls (cs_spawn_probe / cs_spawn_commit)";
+      return 3;
+    }
+    const size_t ns = e->sinks.size();
+    if (ns > e->step_flags_cap) {
+      HIP_OK_E(e, hipStreamSynchronize(e->stream));
+      hipFree(e->step_flags_dev);
+      e->step_flags_dev = nullptr;
+      e->step_flags_cap = ns * 2 + 64;
+      HIP_OK_E(e, hipMalloc(&e->step_flags_dev, e->step_flags_cap * sizeof(int)));
+    }
+    if (int rc = e->spawn_probe_dev(dt_seconds, e->step_flags_dev)) return rc;
+    if (int rc = cs_allreduce_max_i32_rccl(e, e->step_flags_dev, ns)) return rc;
+    if (int rc = e->spawn_commit_dev(e->step_flags_dev)) return rc;
+  }
+  const int rc = e->step(dt_seconds, report);
+  if (rc == 0) e->steps_done += 1;
+  return rc;
 }
 
 }  // extern "C"

@@ -651,6 +651,17 @@ class Simulation:
         if self._lib.cs_allreduce_max_i32_rccl(self._engine, C.c_void_p(dev_ptr), int(n)) != 0:
             raise self._err()
 
+    def tile_step_rccl(self, dur, report=False):
+        """One multi-GPU step of this tile in ONE call into the engine (cs_tile_step_rccl)."""
+        dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
+        rep = _abi.StepReport()
+        rc = self._lib.cs_tile_step_rccl(self._engine, dt, C.byref(rep) if report else None)
+        self._agents_cache = None
+        if report:
+            self.last_report = rep.as_dict()
+        if rc != 0:
+            raise self._err()
+
     def spawn_probe(self, dur):
         """Tile engines: which of MY source-sinks would spawn this step (uint8 flag per sink)."""
         dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)

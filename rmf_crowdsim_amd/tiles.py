@@ -587,6 +587,11 @@ class DistributedTiles(_TileBase):
             raise CrowdSimError("unknown agent id")
 
     def step(self, dur, report=False):
+        if (self.transport == "engine" and self.phases == 1 and not getattr(self, "_host_planner", False) and
+                not self.sim.host_events_needed):
+            # nothing needs the host between the phases: the whole step is one call into the engine
+            self.sim.tile_step_rccl(dur, report=report)
+            return
         with self.torch.cuda.stream(self.stream):
             if self.phases == 2:
                 for axis in (0, 1):

@@ -247,4 +247,5 @@ extern "C" {
     pub fn cs_halo_set_peers(e: *mut cs_engine, peers8: *const i32) -> c_int;
     pub fn cs_halo_exchange_rccl(e: *mut cs_engine, axis: i32) -> c_int;
     pub fn cs_allreduce_max_i32_rccl(e: *mut cs_engine, values_dev: *mut c_int, n: usize) -> c_int;
+    pub fn cs_tile_step_rccl(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
 }
