@@ -68,7 +68,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # development only (tools/variants_bench.sh): time another build of the same engine
+    lib_path = os.environ.get("CS_LIB_PATH") or LIB_PATH
+    if not os.path.exists(lib_path):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). rmf_crowdsim_amd has no CPU fallback.")
@@ -80,5 +82,5 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    _lib = _abi.bind(ctypes.CDLL(LIB_PATH))
+    _lib = _abi.bind(ctypes.CDLL(lib_path))
     return _lib
