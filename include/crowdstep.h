@@ -70,6 +70,15 @@ typedef struct cs_device_cfg {
 #define CS_CFG_DENSE 4u         /* expect more than 64 neighbours in sight somewhere (hotspots):
                                  * neighbour lists of up to 128 entries (more scratch memory);
                                  * chosen automatically when the MEAN occupancy says so */
+#define CS_CFG_TILE_OVERLAP 8u  /* tile engines driven by cs_tile_step_rccl: the windows along the tile's
+                                 * edges run as a launch of their own on a second stream and pack the next
+                                 * step's halo records; that exchange then runs while the interior windows
+                                 * are still being stepped (SURVEY.md section 8e "overlap with K4 on
+                                 * interior cells").  Calls that change agents between two steps
+                                 * (cs_add_agents, cs_remove_agent, cs_tile_import ...) must then be made on
+                                 * every rank alike: they void the exchange made ahead, and all ranks have
+                                 * to repeat it together.  An agent that crosses more than a cell per step
+                                 * into the halo band fails the step (it would miss the exchange). */
 
 /* Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
  *               agent_mass, agent_radius)   local_planners/zanlungo.rs:31-48 */

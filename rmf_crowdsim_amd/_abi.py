@@ -11,6 +11,7 @@ CS_CFG_DEFAULT = 0
 CS_CFG_FORCE_GATHER = 1
 CS_CFG_FORCE_TILED = 2
 CS_CFG_DENSE = 4
+CS_CFG_TILE_OVERLAP = 8
 
 CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK, CS_HLP_ROUTE = 0, 1, 2, 3, 4
 CS_ROUTE_MAX_WAYPOINTS = 1023

@@ -77,6 +77,11 @@ void cs_destroy(cs_engine* e) {
     if (sn.copied) hipEventDestroy(sn.copied);
   }
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+  if (e->aux_stream) {
+    hipStreamSynchronize(e->aux_stream);
+    hipStreamDestroy(e->aux_stream);
+    hipEventDestroy(e->ev_sorted); hipEventDestroy(e->ev_border); hipEventDestroy(e->ev_xchg);
+  }
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
@@ -159,6 +164,8 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_SPILL_ROWS")) e->tile_spill_rows = atoi(v);
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_HALO_FUSE")) e->halo_fuse = atoi(v) != 0;
+  if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
@@ -224,6 +231,7 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
 // another tile may), anything else = the engine's own failure (poisoned, HIP error).
 int cs_remove_agent(cs_engine* e, uint64_t id) {
   hipSetDevice(e->device);
+  e->halo_invalidate();  // also where the agent is not found: every tile is asked, all must agree on what follows
   if (int rc = e->refresh_counts()) return rc;
   uint32_t found[2] = {0xFFFFFFFFu, 0u};
   if (id < 0xFFFFFFFFull && e->n_slots) {
@@ -251,6 +259,7 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
   e->sorted = false;
   e->hist_valid = false;
   e->occ_valid = false;
+  e->halo_invalidate();
   e->n_alive_host -= 1;
   cs_event ev;
   ev.kind = CS_EVENT_DESTROYED;
@@ -680,6 +689,7 @@ int cs_halo_set_buffers(cs_engine* e, uint32_t dir, void* send_dev, void* recv_d
   e->halo[dir].cap = (uint32_t)capacity_records;
   if (dir < 4) e->halo_counts_clean[dir / 2] = false;
   e->halo_all_clean = false;
+  e->halo_invalidate();
   // room for everything the four neighbours may deliver in one step
   return e->reserve((uint64_t)e->n_slots + 1024);
 }
@@ -850,8 +860,22 @@ int cs_halo_set_peers(cs_engine* e, const int32_t* peers8) {
   return 0;
 }
 
+static int halo_exchange_rccl_on(cs_engine* e, int32_t axis, hipStream_t stream);
+
 int cs_halo_exchange_rccl(cs_engine* e, int32_t axis) {
   hipSetDevice(e->device);
+  if (e->exchanged_ahead && axis < 0) {
+    // the previous cs_tile_step_rccl already exchanged this state's halo on its second stream,
+    // behind the border windows' launch: wait for it (in stream order) instead of sending again
+    e->exchanged_ahead = false;
+    return hipStreamWaitEvent(e->stream, e->ev_xchg, 0) == hipSuccess ? 0 : 90;
+  }
+  if (e->aux_stream && e->ev_xchg)  // (an exchange ahead that a later change of the agents made void)
+    if (hipStreamWaitEvent(e->stream, e->ev_xchg, 0) != hipSuccess) return 90;
+  return halo_exchange_rccl_on(e, axis, e->stream);
+}
+
+static int halo_exchange_rccl_on(cs_engine* e, int32_t axis, hipStream_t stream) {
   rccl_api::Api& a = rccl_api::api();
   if (!a.handle || !e->rccl_comm) {
     e->error = a.handle ? "no RCCL communicator: call cs_rccl_comm_init or cs_rccl_comm_adopt first" : a.why;
@@ -868,8 +892,8 @@ int cs_halo_exchange_rccl(cs_engine* e, int32_t axis) {
     const cs_engine::HaloDir& h = e->halo[d];
     if (!h.send || !h.recv || e->halo_peer[d] < 0) continue;
     const size_t bytes = ((size_t)h.cap + 1u) * sizeof(HaloRecord);
-    good = rccl_api::ok(e, a.send(h.send, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, e->stream), "ncclSend") &&
-           rccl_api::ok(e, a.recv(h.recv, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, e->stream), "ncclRecv");
+    good = rccl_api::ok(e, a.send(h.send, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, stream), "ncclSend") &&
+           rccl_api::ok(e, a.recv(h.recv, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, stream), "ncclRecv");
   }
   const int end_rc = a.group_end();  // always close the group
   e->prof_end();
@@ -921,8 +945,18 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
     if (int rc = cs_allreduce_max_i32_rccl(e, e->step_flags_dev, ns)) return rc;
     if (int rc = e->spawn_commit_dev(e->step_flags_dev)) return rc;
   }
+  // CS_CFG_TILE_OVERLAP: the step puts the border windows' launch on the second stream; the next
+  // step's exchange follows them there while the interior windows still run on the engine's stream
+  e->overlap_ready = e->split_margin() != 0u && e->rccl_comm != nullptr;
   const int rc = e->step(dt_seconds, report);
+  e->overlap_ready = false;
   if (rc == 0) e->steps_done += 1;
+  if (rc == 0 && e->border_on_aux && e->halo_prepacked) {
+    e->border_on_aux = false;
+    if (int rc2 = halo_exchange_rccl_on(e, -1, e->aux_stream)) return rc2;
+    HIP_OK_E(e, hipEventRecord(e->ev_xchg, e->aux_stream));
+    e->exchanged_ahead = true;
+  }
   return rc;
 }
 

@@ -17,6 +17,7 @@ pub const CS_CFG_DEFAULT: u32 = 0;
 pub const CS_CFG_FORCE_GATHER: u32 = 1;
 pub const CS_CFG_FORCE_TILED: u32 = 2;
 pub const CS_CFG_DENSE: u32 = 4;
+pub const CS_CFG_TILE_OVERLAP: u32 = 8;
 
 pub const CS_HLP_NONE: u32 = 0;
 pub const CS_HLP_CONSTANT: u32 = 1;

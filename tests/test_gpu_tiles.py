@@ -77,6 +77,52 @@ def test_creeping_counterflow_across_tiles():
     assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("tiles,halo,cell", [((2, 2), 1, 2.0), ((3, 1), 1, 2.0), ((2, 2), 2, 1.0)])
+def test_border_and_interior_launches_match_single_engine(tiles, halo, cell, monkeypatch):
+    """CS_CFG_TILE_OVERLAP's work decomposition on one stream (CS_TILE_SPLIT=1): the windows along a
+    tile's edges run as a launch of their own and pack the next step's halo records (the step
+    kernel's epilogue, no pack launch), the interior windows as a second launch.  Walkers that
+    cross cells and tiles, with the social force: same bits as one engine."""
+    monkeypatch.setenv("CS_TILE_SPLIT", "1")
+    n = 30000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=5, cell_size=cell, margin=20.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    vel = [(1.30, 0.4), (1.28, 0.4)]
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo)
+    for t in (single, mesh):
+        _populate(t, pts, group, vel, lp, 2.0)
+    for k in range(80):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=(k % 17 == 0))
+        if k == 40:  # a change between two steps voids what the step kernel packed: the pack launch runs again
+            extra = np.array([[grid["offset"][0] + 3.0, grid["offset"][1] + 3.0]])
+            for t in (single, mesh):
+                t.add_agents(extra, StubHighLevelPlan((0.5, 0.5)), lp, 2.0)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(b) == n + 1
+    assert a.tobytes() == b.tobytes()
+
+
+def test_an_agent_that_outruns_the_border_launch_fails_the_step(monkeypatch):
+    """With the border windows launched ahead of the interior ones, an interior agent that reaches the
+    halo band within one step (more than a cell per step) would miss the exchange: the engine says so
+    instead of letting the tiles drift apart."""
+    from rmf_crowdsim_amd.simulation import CrowdSimError
+    monkeypatch.setenv("CS_TILE_SPLIT", "1")
+    n = 20000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=3, cell_size=2.0, margin=40.0)
+    # a ghost ring of 3 cells: 4.5 m per step (cells of 2 m) stays inside the local grid, so the
+    # step itself is legal on a tile; what fails is the overlap's assumption
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 1), halo_cells=3)
+    # (everyone at the same velocity: no time to collision is finite, the social force stays zero)
+    _populate(mesh, pts, group, [(90.0, 0.0), (90.0, 0.0)], Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+    with pytest.raises(CrowdSimError, match="halo band"):
+        for _ in range(6):
+            mesh.step(0.05, report=False)
+        mesh.read_agents()
+
+
 def test_hotspot_crowd_with_weighted_cuts_matches_single_engine():
     """BASELINE.json configs[4] in miniature: clustered crowd (cells of up to ~45 agents, far more
     neighbours in sight than a neighbour list holds), tile cuts at the histogram quantiles."""
@@ -381,9 +427,14 @@ def _rank_nccl_single(port, out_path):
                 ok = ok and bool((recv == k).all().item())
         grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
         results = {}
-        for transport in ("engine", "torch"):
-            tiles = DistributedTiles(LocationHash2D(**grid), (1, 1), halo_cells=1, device=0, transport=transport)
-            assert tiles.transport == transport
+        for transport in ("engine", "torch", "overlap"):
+            # "overlap": CS_CFG_TILE_OVERLAP through cs_tile_step_rccl: the border windows' launch on the
+            # engine's second stream (no neighbours here, so nothing is sent: the streams and events are
+            # what this covers; the border / interior decomposition itself is tested on LocalTileMesh)
+            tiles = DistributedTiles(LocationHash2D(**grid), (1, 1), halo_cells=1, device=0,
+                                     transport="engine" if transport == "overlap" else transport,
+                                     flags=8 if transport == "overlap" else 0)
+            assert tiles.transport == ("engine" if transport == "overlap" else transport)
             _sink_scene(tiles)
             for k in range(400):
                 tiles.step(0.05, report=(k in (150, 151)))  # flags all-reduced on the device, twice via the host
@@ -424,6 +475,7 @@ def _rank_nccl_single(port, out_path):
                 sent = [int(bufs[d][0][:4].cpu().numpy().view("<u4")[0]) for d in (XLO, XHI)]
                 recv_bytes[transport] = recv_bytes[transport] and min(sent) > 20
         checks = {"stream_order": ok, "mesh_engine_vs_torch": results["engine"].tobytes() == results["torch"].tobytes(),
+                  "overlap_streams": results["overlap"].tobytes() == results["engine"].tobytes(),
                   "self_exchange_engine": recv_bytes["engine"], "self_exchange_torch": recv_bytes["torch"]}
         print("rccl checks:", checks, "records sent", sent, flush=True)
         ok = all(checks.values())
