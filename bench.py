@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--no-creep-leg", action="store_true",
                     help="skip the short run of the creep scene whose kernel time is reported beside the default one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="--gpus > 1: CS_CFG_TILE_OVERLAP (the next step's halo exchange runs behind the border "
+                         "windows' launch on a second stream while the interior windows are stepped)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
     ap.add_argument("--planner", choices=["stub", "route"], default="stub",
                     help="stream workload: constant-velocity stub planners (the reference tests' kind) or "
@@ -189,6 +192,8 @@ def main():
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
     if args.workload == "hotspots":
         flags |= _abi.CS_CFG_DENSE  # more than 64 neighbours in sight in the cores
+    if args.overlap and world > 1:
+        flags |= _abi.CS_CFG_TILE_OVERLAP
 
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
     from rmf_crowdsim_amd.tiles import DistributedTiles, default_tiling
@@ -409,7 +414,7 @@ def main():
                 "speed": speed, "kernel": args.kernel,
                 "parallelism": "1 GPU" if world == 1 else
                 f"{tiling[0]}x{tiling[1]} spatial tiles, one per GPU, one halo exchange with the (up to) 8 neighbours over "
-                f"{backend} send/recv",
+                f"{backend} send/recv" + (", exchange overlapped with the interior windows" if args.overlap else ""),
                 "n_tti_zero": int(t_n[1].item()), "n_nonfinite": int(t_n[2].item()),
                 "n_agents_alive": alive_all,
                 "profile_key": key,
