@@ -69,7 +69,7 @@ void cs_destroy(cs_engine* e) {
   e->free_arrays(e->buf[0]);
   e->free_arrays(e->buf[1]);
   hipFree(e->pref); hipFree(e->cell_count); hipFree(e->cell_start); hipFree(e->block_totals);
-  hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->epi_dev); hipHostFree(e->epi_host); hipFree(e->destroyed); hipFree(e->wp_events);
+  hipFree(e->ctr); hipHostFree(e->ctr_host); hipFree(e->epi_dev); delete[] e->epi_host; hipFree(e->destroyed); hipFree(e->wp_events);
   for (auto& sn : e->snap) {
     if (sn.in_flight) hipEventSynchronize(sn.copied);
     hipFree(sn.dev); hipHostFree(sn.host); hipFree(sn.count_dev); hipHostFree(sn.count_host);
