@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--no-creep-leg", action="store_true",
                     help="skip the short run of the creep scene whose kernel time is reported beside the default one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="hipEvent pair around the neighbour kernel at every N-th timed step (a pair costs the stream "
+                         "a few us: at small crowds use a larger stride)")
     ap.add_argument("--overlap", action="store_true",
                     help="--gpus > 1: CS_CFG_TILE_OVERLAP (the next step's halo exchange runs behind the border "
                          "windows' launch on a second stream while the interior windows are stepped)")
@@ -278,7 +281,7 @@ def main():
     sim.profile_reset()
     # hipEvents around K4 on the engine's stream; every 4th launch of the timed region, since an
     # event pair costs the stream ~6 us per step
-    sim.profile_stride(4)
+    sim.profile_stride(max(1, args.profile_stride))
     sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
     sync_all()
     t0 = time.perf_counter()

@@ -148,16 +148,14 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, e->device);
   e->backend = std::string("hip:") + prop.gcnArchName;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_tiled),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-    (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
-  {  // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB
+  for (const void* fn : {reinterpret_cast<const void*>(k_step_tiled<false>), reinterpret_cast<const void*>(k_step_tiled<true>)}) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+      (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
+    // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB
     hipFuncAttributes fa;
-    size_t st = 0;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_step_tiled)) == hipSuccess)
-      st = std::max(st, (size_t)fa.sharedSizeBytes);
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes)
+      e->tile_static_lds = std::max(e->tile_static_lds == 512u ? 0u : e->tile_static_lds, (uint32_t)fa.sharedSizeBytes);
     (void)hipGetLastError();
-    if (st) e->tile_static_lds = (uint32_t)st;
   }
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_MIN_ROWS")) e->tile_min_rows = (uint32_t)atoi(v);

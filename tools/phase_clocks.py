@@ -16,7 +16,7 @@ ap.add_argument("--agents", type=int, default=1_000_000)
 ap.add_argument("--eyesight", type=float, default=2.0)
 ap.add_argument("--cell", type=float, default=2.0)
 ap.add_argument("--steps", type=int, default=50)
-ap.add_argument("--workload", choices=["uniform", "hotspots", "random"], default="uniform")
+ap.add_argument("--workload", choices=["uniform", "hotspots", "random", "walk"], default="uniform")
 args = ap.parse_args()
 
 os.environ["CS_HIPCC_EXTRA"] = "-DCS_PHASE_CLOCKS"
@@ -29,10 +29,17 @@ try:
     from rmf_crowdsim_amd.simulation import IdParityHighLevelPlan, Simulation, Zanlungo  # noqa: E402
 
     crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload, scenes.uniform_crowd)
-    pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
+    if args.workload == "walk":  # bench.py's default: the crowd walks +x, with room on that side
+        room = scenes.WALK_SPEED * 0.05 * (args.steps + 18) + 4.0
+        pts, grid, extent, group = scenes.uniform_crowd(args.agents, seed=7, cell_size=args.cell, room=room)
+    else:
+        pts, grid, extent, group = crowd(args.agents, seed=7, cell_size=args.cell)
     from rmf_crowdsim_amd.simulation import LocationHash2D
     sim = Simulation(LocationHash2D(**grid), flags=4 if args.workload == "hotspots" else 0)  # 4 = CS_CFG_DENSE
-    scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, Zanlungo(*scenes.METRIC_ZANLUNGO), args.eyesight)
+    if args.workload == "walk":
+        scenes.add_walking_crowd(sim, pts, group, Zanlungo(*scenes.METRIC_ZANLUNGO), args.eyesight)
+    else:
+        scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, Zanlungo(*scenes.METRIC_ZANLUNGO), args.eyesight)
     for _ in range(10):
         sim.step(0.05, report=False)
     lib = sim._lib
