@@ -55,6 +55,7 @@ try:
              "staging: barrier 2", "agent setup", "filter", "time-to-collision", "forces", "epilogue"]
     total = float(sum(out[:11])) or 1.0
     print(f"agents {args.agents} eyesight {args.eyesight} cell {args.cell}: wave cycles per step {total / args.steps:.4g}")
+    print(f"  windows per step off the LDS path: {(out[11] & 0xFFFFFFFF) / 4.0 / args.steps:.2f}, walked in chunks: {(out[11] >> 32) / 4.0 / args.steps:.2f}")
     for n, v in zip(names, out):
         print(f"  {n:18s} {100.0 * v / total:5.1f} %   {v / args.steps / (args.agents / 64.0):8.0f} cycles per wave of 64 agents")
 finally:
