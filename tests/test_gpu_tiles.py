@@ -582,8 +582,8 @@ def test_removals_on_a_tile_mesh_match_the_single_engine():
     assert sorted(heard_s.removed) == sorted(heard_m.removed)
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_meshes_match_the_single_engine(seed):
+@pytest.mark.parametrize("seed,split", [(k, False) for k in range(24)] + [(k, True) for k in range(0, 24, 2)])
+def test_random_meshes_match_the_single_engine(seed, split, monkeypatch):
     """Random grids, cell sizes, eyesight ranges (halo up to 7 cells), mesh shapes, exchange
     schedules, walking speeds and planners: same bits as one engine, and the same failures (the
     reference model leaves its finite range at walking speed, DESIGN.md section 5: then both
@@ -594,6 +594,8 @@ def test_random_meshes_match_the_single_engine(seed):
     from rmf_crowdsim_amd import CrowdSimError
     from rmf_crowdsim_amd.simulation import IdParityHighLevelPlan
     from test_gpu_parity import _fuzz_case
+    if split:  # the border windows as a launch of their own, packing the next exchange (one-phase schedule)
+        monkeypatch.setenv("CS_TILE_SPLIT", "1")
     rng = np.random.default_rng(5000 + seed)
     grid, pts, eyesight, speed, spacing = _fuzz_case(3000 + seed)
     cell = grid["cell_size"]
@@ -608,6 +610,8 @@ def test_random_meshes_match_the_single_engine(seed):
     lp = Zanlungo(1.0, 1.0, 0.0, 2.0 * R, 2.0, R) if rng.random() < 0.7 else NoLocalPlan()
     walk = float(rng.choice([0.01, 0.3, 1.3]))
     phases = int(rng.choice([1, 2]))
+    if split:
+        phases = 1
     single = Simulation(LocationHash2D(**grid))
     mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, phases=phases)
     n = len(pts)
@@ -774,8 +778,8 @@ def test_random_source_sinks_engine_oracle_and_mesh_agree(seed):
     assert len(a) == 0 or max_rel_err(a[ok], b[ok], 80.0) <= 1e-4
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed):
+@pytest.mark.parametrize("seed,split", [(k, False) for k in range(12)] + [(k, True) for k in range(1, 12, 2)])
+def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed, split, monkeypatch):
     """Sixty random calls per run on a mesh (random shape, halo, even or weighted cuts, either
     exchange schedule) and on one engine: agents added in mid-run (some hugging the cuts),
     removals, source-sinks added in mid-run, steps with and without a report; kinematic walkers or
@@ -783,6 +787,8 @@ def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed):
     bits at the end."""
     import math
     from rmf_crowdsim_amd import CrowdSimError, SeededPoissonCrowd, SourceSink
+    if split:  # border / interior launches; every add / remove between steps voids what the border launch packed
+        monkeypatch.setenv("CS_TILE_SPLIT", "1")
     rng = np.random.default_rng(15000 + seed)
     cell = float(rng.choice([1.0, 2.0, 2.5])); side = float(rng.choice([40.0, 60.0, 80.0]))
     grid = dict(width=side, height=side, cell_size=cell, offset=(float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))))
@@ -792,7 +798,8 @@ def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed):
     if min(ncell // tiles[0], ncell // tiles[1]) < 2 * halo + 2: tiles = (2, 1)
     w = rng.normal(side / 2, side / 6, size=(2000, 2)).clip(1, side - 1) + off if rng.random() < 0.5 else None
     single = Simulation(LocationHash2D(**grid))
-    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, weights=w, phases=int(rng.choice([1, 2])))
+    phases = int(rng.choice([1, 2]))
+    mesh = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, weights=w, phases=1 if split else phases)
     kin = rng.random() < 0.5
     lp = NoLocalPlan() if kin else Zanlungo(*scenes.METRIC_ZANLUNGO)
     speed, dt = (1.0, 0.1) if kin else (0.002, 0.05)
