@@ -21,6 +21,7 @@
 // resolution at any domain size.  f64 appears only at the ABI.
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -77,6 +78,7 @@ void cs_destroy(cs_engine* e) {
     if (sn.copied) hipEventDestroy(sn.copied);
   }
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+  if (e->peek_host) hipHostFree(e->peek_host);
   if (e->aux_stream) {
     hipStreamSynchronize(e->aux_stream);
     hipStreamDestroy(e->aux_stream);
@@ -163,6 +165,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_SPILL_ROWS")) e->tile_spill_rows = atoi(v);
   if (const char* v = getenv("CS_TILE_AGENTS_SLACK")) e->tile_agents_slack = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_HALO_FUSE")) e->halo_fuse = atoi(v) != 0;
+  if (const char* v = getenv("CS_TILE_ASYNC")) e->kTileAsync = (uint32_t)std::max(1, atoi(v));
   if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
