@@ -146,6 +146,11 @@ def main():
     ap.add_argument("--no-creep-leg", action="store_true",
                     help="skip the short run of the creep scene whose kernel time is reported beside the default one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-warmup", type=int, default=60,
+                    help="the device gets at least this many untimed steps of the same scene before the timed region "
+                         "(the W warm-up steps count towards it): after a handful of steps the clocks have not settled "
+                         "and the first timed steps run 7-10 %% slow (20 timed steps after 5: 5.3e9, after 100: 5.8e9); "
+                         "reported as config.clock_warmup_steps")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="hipEvent pair around the neighbour kernel at every N-th timed step (a pair costs the stream "
                          "a few us: at small crowds use a larger stride)")
@@ -188,8 +193,9 @@ def main():
     # step fails with "Index out of bounds", on the reference's f64 path as well (DESIGN.md
     # section 5).  The kernel's cost does not depend on the speed scale (measured: 1e-3, 1e-4 and 1e-5 m/s
     # give the same time), so long runs creep slower: at most 2.5 cm of closing over the run.
+    clock_warmup = max(0, args.clock_warmup - args.warmup)  # extra untimed steps before the W warm-up steps
     if args.speed is None:
-        speed = min(scenes.CREEP_SPEED, 0.25 / (args.steps + args.warmup + 2))
+        speed = min(scenes.CREEP_SPEED, 0.25 / (args.steps + args.warmup + clock_warmup + 2))
     else:
         speed = args.speed
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
@@ -205,7 +211,7 @@ def main():
     tile_report = {}
     uniform_kind = args.workload in ("walk", "creep")
     crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload)
-    total_steps = args.steps + args.warmup + 2
+    total_steps = args.steps + args.warmup + clock_warmup + 2
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
@@ -275,7 +281,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(clock_warmup + args.warmup):
         stepper.step(0.05, report=False)
     sim.synchronize()
     sim.profile_reset()
@@ -420,6 +426,7 @@ def main():
                 f"{backend} send/recv" + (", exchange overlapped with the interior windows" if args.overlap else ""),
                 "n_tti_zero": int(t_n[1].item()), "n_nonfinite": int(t_n[2].item()),
                 "n_agents_alive": alive_all,
+                "clock_warmup_steps": clock_warmup,
                 "profile_key": key,
                 **tile_report,
             },
