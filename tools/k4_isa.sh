@@ -6,7 +6,7 @@ mkdir -p /tmp/isa && cd /tmp/isa && rm -f *.s *.bc *.o *.out *.hipi
   -mllvm -amdgpu-sched-strategy=iterative-ilp -fno-unroll-loops -gline-tables-only -save-temps -w "$@" \
   -I /root/repo/include -o /tmp/isa/lib.so /root/repo/rmf_crowdsim_amd/csrc/crowdstep_hip.hip 2>&1 | grep -A5 "error" | head -30
 S=/tmp/isa/crowdstep_hip-hip-amdgcn-amd-amdhsa-gfx950.s
-for k in k_step_tiled k_step_gather; do
+for k in k_step_tiledILb0 k_step_tiledILb1 k_step_gather; do
 python3 /root/repo/tools/isa_by_line.py $S $k | head -1
-awk -v k="$k" '$0 ~ "^_Z[0-9]+"k {f=1} f&&/; (TotalNumSgprs|NumVgprs|ScratchSize|Occupancy|LDSByteSize)/{print} f&&/; LDSByteSize/{exit}' $S | tr '\n' ' '; echo
+echo -n "$k: "; awk -v k="$k" '$0 ~ "^_Z[0-9]+"k {f=1} f&&/; (TotalNumSgprs|NumVgprs|ScratchSize|Occupancy|LDSByteSize)/{print} f&&/; LDSByteSize/{exit}' $S | tr '\n' ' '; echo
 done
