@@ -30,6 +30,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
