@@ -304,6 +304,18 @@ int cs_query_knn_batch(cs_engine*, size_t n, const double* xy, size_t k, uint64_
  * the number of source-sinks and routes, never with the number of steps or of ids handed out. */
 uint64_t cs_device_bytes(cs_engine*);
 
+/* How the LDS-tiled neighbour kernel has fared since the engine was created (waits for the device):
+ * CS_STAT_WINDOWS_OFF_LDS  band windows whose staged tile did not fit the LDS (or the fixed-point
+ *                          range) and whose agents therefore took the gather path, one slow workgroup
+ *                          each: the window builder bounds a window by what it stages, so this stays 0
+ *                          unless single cells are overfull;
+ * CS_STAT_WINDOWS_CHUNKED  windows that held more than a workgroup's 256 agents and were walked in
+ *                          chunks.
+ * Diagnostics of the engine's own work decomposition; the reference has no counterpart. */
+#define CS_STAT_WINDOWS_OFF_LDS 0u
+#define CS_STAT_WINDOWS_CHUNKED 1u
+uint64_t cs_kernel_stat(cs_engine*, uint32_t which);
+
 /* ---- measurement (bench.py / rocprof cross-check) ---------------------- */
 /* Kernel names the engine launches per step, for HIP-event timing. */
 enum {

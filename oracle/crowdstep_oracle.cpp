@@ -894,6 +894,7 @@ uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
 void cs_remove_source_sink(cs_engine* e, uint32_t handle) { e->source_sinks.erase(handle); }
 size_t cs_source_sink_slots(cs_engine* e) { return e->next_sink_handle; }
 uint64_t cs_device_bytes(cs_engine*) { return 0; }
+uint64_t cs_kernel_stat(cs_engine*, uint32_t) { return 0; }  // (the HIP engine's own diagnostics)
 // batch forms: the single queries in a loop (location_hash_2d.rs:240-258, :151-238)
 size_t cs_query_radius(cs_engine* e, double radius, double x, double y, uint64_t* out_ids, size_t cap);
 size_t cs_query_knn(cs_engine* e, size_t k, double x, double y, uint64_t* out_ids);

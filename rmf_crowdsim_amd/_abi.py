@@ -12,6 +12,8 @@ CS_CFG_FORCE_GATHER = 1
 CS_CFG_FORCE_TILED = 2
 CS_CFG_DENSE = 4
 CS_CFG_TILE_OVERLAP = 8
+CS_STAT_WINDOWS_OFF_LDS = 0
+CS_STAT_WINDOWS_CHUNKED = 1
 
 CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK, CS_HLP_ROUTE = 0, 1, 2, 3, 4
 CS_ROUTE_MAX_WAYPOINTS = 1023
@@ -126,6 +128,7 @@ SYMBOLS = {
     "cs_remove_source_sink": (None, [C.c_void_p, C.c_uint32]),
     "cs_source_sink_slots": (C.c_size_t, [C.c_void_p]),
     "cs_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "cs_kernel_stat": (C.c_uint64, [C.c_void_p, C.c_uint32]),
     "cs_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
     "cs_synchronize": (C.c_int, [C.c_void_p]),
     "cs_agent_count": (C.c_size_t, [C.c_void_p]),

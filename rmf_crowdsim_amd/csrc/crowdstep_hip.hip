@@ -275,6 +275,13 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
 size_t cs_source_sink_slots(cs_engine* e) { return e->sinks.size(); }
 uint64_t cs_device_bytes(cs_engine* e) { return e->device_bytes(); }
 
+uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
+  hipSetDevice(e->device);
+  Counters c;
+  if (e->read_counters(&c)) return 0;
+  return which == CS_STAT_WINDOWS_OFF_LDS ? c.n_win_off_lds : which == CS_STAT_WINDOWS_CHUNKED ? c.n_win_chunked : 0;
+}
+
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
   if (e->groups.size() + 1 >= CS_MAX_GROUPS || d->n_waypoints == 0 || d->n_waypoints > 65535) {
     e->error = "too many source-sinks / planner groups (65535) or bad waypoint count";

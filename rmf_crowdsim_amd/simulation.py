@@ -678,6 +678,11 @@ class Simulation:
         """Device memory held by the engine (grows with capacity, never with steps or ids)."""
         return int(self._lib.cs_device_bytes(self._engine))
 
+    def kernel_stat(self, which):
+        """Diagnostics of the tiled kernel's work decomposition since creation (cs_kernel_stat):
+        0 = windows that left the LDS path, 1 = windows walked in chunks."""
+        return int(self._lib.cs_kernel_stat(self._engine, int(which)))
+
     @property
     def source_sink_slots(self):
         """Source-sink handles handed out so far (removed sinks keep their slot)."""

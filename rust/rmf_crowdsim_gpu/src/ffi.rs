@@ -18,6 +18,8 @@ pub const CS_CFG_FORCE_GATHER: u32 = 1;
 pub const CS_CFG_FORCE_TILED: u32 = 2;
 pub const CS_CFG_DENSE: u32 = 4;
 pub const CS_CFG_TILE_OVERLAP: u32 = 8;
+pub const CS_STAT_WINDOWS_OFF_LDS: u32 = 0;
+pub const CS_STAT_WINDOWS_CHUNKED: u32 = 1;
 
 pub const CS_HLP_NONE: u32 = 0;
 pub const CS_HLP_CONSTANT: u32 = 1;
@@ -211,6 +213,7 @@ extern "C" {
     pub fn cs_remove_source_sink(e: *mut cs_engine, handle: u32);
     pub fn cs_source_sink_slots(e: *mut cs_engine) -> usize;
     pub fn cs_device_bytes(e: *mut cs_engine) -> u64;
+    pub fn cs_kernel_stat(e: *mut cs_engine, which: u32) -> u64;
     pub fn cs_step(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
     pub fn cs_synchronize(e: *mut cs_engine) -> c_int;
     pub fn cs_agent_count(e: *mut cs_engine) -> usize;

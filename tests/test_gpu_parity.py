@@ -386,6 +386,41 @@ def test_band_windows_stay_within_the_launch_when_the_staging_bound_cuts_them(st
     assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
 
 
+@pytest.mark.parametrize("scene", ["walking edge", "cell 4 m", "hotspots", "cell 1 m, eyesight 2 m"])
+def test_every_window_stays_on_the_lds_path(scene):
+    """The window builder bounds a window by what it STAGES (its own rows and columns plus the ghost
+    rows and halo columns around them).  Bounding the owned agents alone, with the ghost rows assumed
+    equally full, let windows overflow the LDS tile wherever a sparse band lies beside dense rows:
+    at the leading and trailing edge of a walking crowd (12 steps out of every 30, as the edge
+    crosses a cell row), and in every window of a grid with wide cells; their agents then took the
+    gather path, one ~100 us workgroup at the kernel's tail.  cs_kernel_stat counts such windows."""
+    from rmf_crowdsim_amd import _abi
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    if scene == "walking edge":
+        steps = 70  # more than one cell row of travel: every alignment of the crowd's edges with the grid
+        pts, grid, extent, group = scenes.uniform_crowd(125000, seed=7, cell_size=2.0,
+                                                        room=scenes.WALK_SPEED * 0.05 * (steps + 8) + 4.0)
+        sim = Simulation(LocationHash2D(**grid), flags=2)
+        scenes.add_walking_crowd(sim, pts, group, lp, 2.0)
+    elif scene == "hotspots":
+        steps = 5
+        pts, grid, extent, group = scenes.hotspot_crowd(200000, seed=7, cell_size=2.0)
+        sim = Simulation(LocationHash2D(**grid), flags=2 | _abi.CS_CFG_DENSE)
+        scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    else:
+        steps = 5
+        cell = 4.0 if scene == "cell 4 m" else 1.0
+        pts, grid, extent, group = scenes.uniform_crowd(200000, seed=7, cell_size=cell)
+        sim = Simulation(LocationHash2D(**grid), flags=2)
+        scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    for _ in range(steps):
+        sim.step(0.05, report=False)
+    sim.synchronize()
+    assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_OFF_LDS) == 0
+    assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_CHUNKED) == 0
+    assert len(sim) == len(pts)
+
+
 @pytest.mark.parametrize("crowd", ["random", "hotspots"])
 def test_tiled_and_gather_kernels_agree_bitwise_when_lists_overflow(crowd, monkeypatch):
     """Crowds whose neighbour counts scatter: some lanes hold more neighbours than the LDS list
