@@ -778,7 +778,8 @@ def test_random_source_sinks_engine_oracle_and_mesh_agree(seed):
     assert len(a) == 0 or max_rel_err(a[ok], b[ok], 80.0) <= 1e-4
 
 
-@pytest.mark.parametrize("seed,split", [(k, False) for k in range(12)] + [(k, True) for k in range(1, 12, 2)])
+@pytest.mark.parametrize("seed,split", [(k, False) for k in range(12)] + [(k, True) for k in range(1, 12, 2)] +
+                         [(131, True)])  # (131: agents three cells from the DOMAIN's edge, where no neighbour waits for records)
 def test_random_call_sequences_on_a_mesh_match_the_single_engine(seed, split, monkeypatch):
     """Sixty random calls per run on a mesh (random shape, halo, even or weighted cuts, either
     exchange schedule) and on one engine: agents added in mid-run (some hugging the cuts),
