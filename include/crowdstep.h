@@ -77,8 +77,10 @@ typedef struct cs_device_cfg {
                                  * interior cells").  Calls that change agents between two steps
                                  * (cs_add_agents, cs_remove_agent, cs_tile_import ...) must then be made on
                                  * every rank alike: they void the exchange made ahead, and all ranks have
-                                 * to repeat it together.  An agent that crosses more than a cell per step
-                                 * into the halo band fails the step (it would miss the exchange). */
+                                 * to repeat it together.  An agent of an interior window that lands in the halo
+                                 * band within one step fails the step (it would miss the exchange): one that
+                                 * moves more than a cell per step, or whose position turns NaN (the reference
+                                 * bins NaN to cell 0, location_hash_2d.rs:54-66, which on a tile is a ghost cell). */
 
 /* Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
  *               agent_mass, agent_radius)   local_planners/zanlungo.rs:31-48 */
