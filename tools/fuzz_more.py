@@ -21,6 +21,38 @@ class Env:
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "mesh"
+if which == "parity":  # the engine against the oracle (tests/test_gpu_parity.py), further seeds
+    import test_gpu_parity as P
+    ran = 0
+    for seed in range(first, last):
+        for fn in (P.test_random_configurations_match_oracle_and_each_other,
+                   P.test_random_removals_and_queries_between_steps_match_the_oracle,
+                   P.test_random_planner_groups_match_oracle_and_each_other,
+                   P.test_random_api_sequences_give_the_oracle_s_results_and_errors):
+            try:
+                fn(seed)
+                ran += 1
+            except pytest.skip.Exception:
+                pass
+            except P.CrowdSimError as err:
+                # a scene that leaves the model's finite range (the test does not expect one): fine if the
+                # ORACLE leaves it too -- the same test with the oracle standing in for the engine
+                engine = P.Simulation
+                P.Simulation = lambda index, flags=0, **kw: P.OracleSimulation(index)
+                try:
+                    fn(seed)
+                    print(f"FAILED {fn.__name__} seed {seed}: the engine raised '{err}', the oracle did not", flush=True)
+                    raise err
+                except P.CrowdSimError as err2:
+                    print(f"  seed {seed}: {fn.__name__}: engine '{err}', oracle '{err2}' (the model left its range)")
+                finally:
+                    P.Simulation = engine
+            except Exception:
+                print(f"FAILED {fn.__name__} seed {seed}", flush=True)
+                raise
+        print(f"seed {seed} ok", flush=True)
+    print(f"{ran} cases passed")
+    sys.exit(0)
 if which == "sinks":  # the source-sink / route-follower scenes (engine, oracle and a mesh), with the env set for the mesh
     ran = 0
     for seed in range(first, last):
