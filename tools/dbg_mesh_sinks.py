@@ -1,6 +1,6 @@
 import os, sys, math
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-os.environ["CS_TILE_SPLIT"] = "1"
+os.environ.setdefault("CS_TILE_SPLIT", "0")
 import numpy as np
 import test_gpu_tiles as T
 from rmf_crowdsim_amd import CrowdSimError, LocationHash2D, Simulation
@@ -19,14 +19,23 @@ for k in range(200):
         mesh.step(0.1)
     except CrowdSimError as e:
         print("step", k, "error", e)
+        for i, e in enumerate(mesh.engines):
+            try:
+                e.synchronize()
+            except CrowdSimError as err:
+                print("tile", i, "raised:", err)
         # the state before the failing step
         for i, a in enumerate(prev):
             r = mesh.layout.rect(*mesh.layout.coords(i))
             cx = np.floor(a["x"] / cell).astype(int); cy = np.floor(a["y"] / cell).astype(int)
             dx = np.minimum(cx - r[0], r[1] - 1 - cx); dy = np.minimum(cy - r[2], r[3] - 1 - cy)
             print("tile", i, "rect", r, "n", len(a), "min dist to edge x", dx.min() if len(a) else None, "y", dy.min() if len(a) else None)
-            near = (dx <= halo + 1) | (dy <= halo + 1)
-            print("  agents within halo+1 of an edge:", a[near][["id", "x", "y", "vx", "vy"]][:12])
+            # distance to the tile's LOCAL grid boundary (rect + ring, clipped to the domain)
+            n_cells = int(grid["width"] / cell)
+            l0, l1 = max(r[0] - halo, 0), min(r[1] + halo, n_cells); m0, m1 = max(r[2] - halo, 0), min(r[3] + halo, n_cells)
+            ex = np.minimum(a["x"] / cell - l0, l1 - a["x"] / cell); ey = np.minimum(a["y"] / cell - m0, m1 - a["y"] / cell)
+            order = np.argsort(np.minimum(ex, ey))[:6]
+            print("  closest to the local grid's boundary:", [(int(a["id"][j]), round(float(a["x"][j]), 3), round(float(a["y"][j]), 3), round(float(a["vx"][j]), 3), round(float(a["vy"][j]), 3)) for j in order])
         break
     prev = [e.read_agents() for e in mesh.engines]
 else:
