@@ -287,8 +287,9 @@ def main():
     sim.profile_reset()
     # hipEvents around K4 on the engine's stream; every 4th launch of the timed region, since an
     # event pair costs the stream ~6 us per step
-    sim.profile_stride(max(1, args.profile_stride))
-    sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
+    # (tiles: also the halo regions of the step, exchange and unpack in turn: an odd stride times both kinds)
+    sim.profile_stride(max(1, args.profile_stride | 1 if world > 1 else args.profile_stride))
+    sim.profile_enable((1 << _abi.CS_K_NEIGHBOUR_FORCE) | ((1 << _abi.CS_K_HALO) if world > 1 else 0))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -328,6 +329,10 @@ def main():
         raise SystemExit(f"bench: {alive_all} of {n_total} agents alive after the run")
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
+    if world > 1 and prof["halo"]["launches"]:
+        # rank 0's halo exchange + unpack per step, device time between hipEvents on the engine's stream (with
+        # --overlap the exchange runs on the second stream and what is seen here is the wait for it)
+        tile_report["halo_ms_per_step_rank0"] = 2.0 * prof["halo"]["total_ms"] / prof["halo"]["launches"]
     ncells = int(round(grid["width"] / grid["cell_size"])) ** 2 // world  # per tile
     agents_here = rep["n_agents"] if args.workload == "stream" else per_gpu
     alg_bytes = agents_here * (K4_READ_BYTES + K4_WRITE_BYTES) + K4_CELL_BYTES * ncells
