@@ -7,8 +7,11 @@ resident in HBM before the timed region; nothing is read back inside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--agents A] [--eyesight E] [--cell C]
 
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
-one rank per GPU, weak scaling (every rank steps its own --agents crowd).
+N > 1: one rank per GPU.  Either under a launcher (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`, what the driver does) or as plain `python bench.py --gpus N`, which starts that
+launcher itself as a child process before anything touches the GPU.  The default is STRONG scaling:
+--agents (1M) agents in all, one spatial tile per rank (BASELINE.json configs[2]); the weak-scaled figure
+(N x --agents) is timed after it and reported under `weak_scaled`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -130,10 +133,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--agents", type=int, default=1_000_000,
-                    help="agents per GPU (weak scaling) or in all (--scaling strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: every rank adds --agents agents to one crowd; strong: --agents agents in all, "
-                         "cut into one tile per rank (BASELINE.json configs[2]: 1M agents, 4 x 2 tiles on 8 GPUs)")
+                    help="agents in all (strong scaling, the default) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default): --agents agents IN ALL, cut into one tile per rank (the metric's "
+                         "configuration, BASELINE.json configs[2]: 1M agents, 4 x 2 tiles on 8 GPUs); weak: every rank "
+                         "adds --agents agents to one crowd.  With N > 1 the other mode is timed as well and reported "
+                         "under `weak_scaled` / `strong_scaled`")
+    ap.add_argument("--no-second-scaling-leg", action="store_true",
+                    help="N > 1: skip the second run in the other scaling mode")
     ap.add_argument("--eyesight", type=float, default=2.0)
     ap.add_argument("--cell", type=float, default=2.0)
     ap.add_argument("--speed", type=float, default=None, help="default: scenes.CREEP_SPEED")
@@ -165,37 +172,97 @@ def main():
                     help="stream a snapshot of all agents to pinned host memory every step (the "
                          "PCIe-inclusive rate; not the headline value)")
     args = ap.parse_args()
+    launch_ranks_if_needed(args)  # --gpus N without a launcher: start the N ranks as a child and exit with its code
 
     import torch
     import torch.distributed as dist
-    from rmf_crowdsim_amd import Simulation, scenes, _abi
+    from rmf_crowdsim_amd import _abi
 
     if args.workload == "uniform":
         args.workload = "creep"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("CS_BENCH_BACKEND", "nccl")  # "gloo": ranks sharing one GPU (tests)
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched as "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    per_gpu = args.agents if args.scaling == "weak" else max(1, args.agents // world)
-    n_total = per_gpu * world
-    device = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench: {world} ranks but {n_dev} visible GPU(s): RCCL needs one device per rank "
+                         f"(CS_BENCH_BACKEND=gloo lets ranks share a device, for functional tests only)")
+    device = local_rank % n_dev if backend != "nccl" else local_rank
     torch.cuda.set_device(device)
-    backend = os.environ.get("CS_BENCH_BACKEND", "nccl")  # "gloo": ranks sharing one GPU (tests)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
+    if args.scaling is None:
+        # the metric is quoted at 1M agents IN ALL (BASELINE.json configs[2]: 4 x 2 tiles of one 1M crowd)
+        args.scaling = "strong"
+    ctx = dict(torch=torch, dist=dist, rank=rank, world=world, device=device, backend=backend)
+
+    main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
+    other_leg = None
+    if world > 1 and not args.no_second_scaling_leg:
+        # the other scaling mode beside the headline (weak: N x --agents agents in one crowd)
+        other = "weak" if args.scaling == "strong" else "strong"
+        leg = run_leg(args, ctx, other, min(args.steps, 100), min(args.warmup, 10), 30, headline=False)
+        other_leg = {"scaling": other, "value": leg["value"], "ms_per_step": leg["ms_per_step"],
+                     "agents_total": leg["total_agents"], "agents_per_gpu": leg["per_gpu"], "steps": leg["steps"],
+                     "kernel_ms": leg["k4_ms"], **leg["tile_report"]}
+
+    if rank == 0:
+        out = main_leg["line"]
+        if other_leg:
+            out[other_leg["scaling"] + "_scaled"] = other_leg
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the N ranks are started as ONE
+    child (`python -m torch.distributed.run`, one rank per GPU) before this process has imported torch
+    or touched the GPU, and this process exits with the child's code.  Under a launcher (WORLD_SIZE set)
+    this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
+    """One timed run of `steps` steps (after `warmup` + clock warm-up untimed ones) under `scaling`.
+    headline=True also builds the JSON line (roofline, creep leg, CPU baselines)."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    rank, world, device, backend = ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
+    from rmf_crowdsim_amd import Simulation, scenes, _abi
+
+    per_gpu = args.agents if scaling == "weak" else max(1, args.agents // world)
+    n_total = per_gpu * world
     # The counter-flow closes the lattice gaps at 2 * speed; once the first pair (of a million)
     # gets within the model's collision distance its t_i -> 0, the force clamps at 1e15 and the
     # step fails with "Index out of bounds", on the reference's f64 path as well (DESIGN.md
     # section 5).  The kernel's cost does not depend on the speed scale (measured: 1e-3, 1e-4 and 1e-5 m/s
     # give the same time), so long runs creep slower: at most 2.5 cm of closing over the run.
-    clock_warmup = max(0, args.clock_warmup - args.warmup)  # extra untimed steps before the W warm-up steps
+    clock_warmup = max(0, clock_warmup_min - warmup)  # extra untimed steps before the W warm-up steps
     if args.speed is None:
-        speed = min(scenes.CREEP_SPEED, 0.25 / (args.steps + args.warmup + clock_warmup + 2))
+        speed = min(scenes.CREEP_SPEED, 0.25 / (steps + warmup + clock_warmup + 2))
     else:
         speed = args.speed
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
@@ -211,13 +278,13 @@ def main():
     tile_report = {}
     uniform_kind = args.workload in ("walk", "creep")
     crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload)
-    total_steps = args.steps + args.warmup + clock_warmup + 2
+    total_steps = steps + warmup + clock_warmup + 2
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
         from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
-        # longer lanes on more GPUs keep the number of sinks (one planner group each) under 65535
-        lane_length = 16.0 * max(1, (world + 1) // 2) if args.scaling == "weak" else 16.0
+        # (longer lanes on more GPUs keep the number of sinks, one planner group each, under the engine's group limit)
+        lane_length = 16.0 * max(1, (world + 1) // 2) if scaling == "weak" else 16.0
         lanes, grid, fill_steps = scenes.stream_lanes(n_total, lane_length=lane_length, cell_size=args.cell)
         extent = grid["width"]
         if world == 1:
@@ -274,6 +341,9 @@ def main():
                            "imbalance_max_over_mean": float(counts.max() / counts.mean())}
         populate(stepper, args.workload, pts, group, speed, lp, args.eyesight)
         del pts, group
+    if world > 1:
+        tile_report["ranks_in_comm"] = dist.get_world_size()
+        tile_report["devices_visible"] = torch.cuda.device_count()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -281,7 +351,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(clock_warmup + args.warmup):
+    for _ in range(clock_warmup + warmup):
         stepper.step(0.05, report=False)
     sim.synchronize()
     sim.profile_reset()
@@ -292,7 +362,7 @@ def main():
     sim.profile_enable((1 << _abi.CS_K_NEIGHBOUR_FORCE) | ((1 << _abi.CS_K_HALO) if world > 1 else 0))
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         stepper.step(0.05, report=False)
         if args.readback:  # frame k is fetched while step k + 1 runs
             sim.snapshot(wait=True)
@@ -333,6 +403,11 @@ def main():
         # rank 0's halo exchange + unpack per step, device time between hipEvents on the engine's stream (with
         # --overlap the exchange runs on the second stream and what is seen here is the wait for it)
         tile_report["halo_ms_per_step_rank0"] = 2.0 * prof["halo"]["total_ms"] / prof["halo"]["launches"]
+    leg = {"value": total_agents * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "total_agents": total_agents,
+           "per_gpu": per_gpu, "steps": steps, "k4_ms": k4_ms, "tile_report": tile_report}
+    if not headline:
+        del stepper, sim
+        return leg
     ncells = int(round(grid["width"] / grid["cell_size"])) ** 2 // world  # per tile
     agents_here = rep["n_agents"] if args.workload == "stream" else per_gpu
     alg_bytes = agents_here * (K4_READ_BYTES + K4_WRITE_BYTES) + K4_CELL_BYTES * ncells
@@ -377,7 +452,8 @@ def main():
         except (OSError, KeyError, ValueError):
             continue
 
-    # the creep scene's kernel time beside the default one (same crowd, standing, non-zero forces)
+    # the creep scene beside the walking one (same crowd, standing, NON-ZERO forces: in the walking scene the
+    # force term is computed in full and underflows to exactly 0)
     creep_leg = None
     if rank == 0 and world == 1 and args.workload == "walk" and not args.no_creep_leg and not args.debug:
         del stepper, sim
@@ -404,17 +480,19 @@ def main():
         del c_sim
 
     if rank == 0:
-        valu_frac = (valu_insts / (k4_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and k4_ms > 0) else None
+        ceiling = valu_ceiling()
+        valu_peak = ceiling["fma_wave_insts_per_s"] if ceiling else VALU_ISSUE_PEAK
+        valu_frac = (valu_insts / (k4_ms * 1e-3) / valu_peak) if (valu_insts and k4_ms > 0) else None
         out = {
             "metric": "agent-steps/sec at 1M agents, dt=0.05 s; % HBM roofline on Zanlungo kernel",
-            "value": total_agents * args.steps / elapsed,
+            "value": total_agents * steps / elapsed,
             "unit": "agent-steps/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -445,12 +523,14 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes": "SURVEY.md 8(d): 32 B read + 16 B written per agent, 8 B per cell",
                 "fused_kernel_bytes_per_launch": fused_bytes,
-                # what actually bounds it: wave64 VALU instructions per launch (PMC) against the chip's
-                # issue rate of one per 2 clocks per SIMD (1024 SIMDs, 2.4 GHz)
+                # what actually bounds it: wave64 VALU instructions per launch (PMC) against the chip's measured
+                # issue rate of independent v_fma_f32 (tools/valu_ceiling.hip -> profiles/rNN/valu_ceiling.json;
+                # the nominal one per 2 clocks per SIMD at 2.4 GHz while no measurement is cached)
                 "bound_actual": "valu_issue",
                 "valu_issue_frac": valu_frac,
                 "valu_wave_insts_per_launch": valu_insts,
-                "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+                "valu_issue_peak_per_s": valu_peak,
+                "valu_ceiling": ceiling,
                 "pmc_source": pmc_source,
                 "note": "HBM is the nominal bound of a neighbour gather; at ~31 neighbours per agent the kernel is "
                         "bound by VALU issue and LDS latency (DESIGN.md section 4); traffic / valu_* are null unless a "
@@ -459,16 +539,30 @@ def main():
         }
         if creep_leg:
             out["creep_scene"] = creep_leg
+            # the same crowd with forces that do not underflow: the figure to quote when the force path must count
+            out["value_full_force"] = creep_leg["value"]
         if not args.no_cpu_baseline:
             wl = args.workload if uniform_kind else "creep"
             out["cpu_baseline"] = cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)
             if uniform_kind:
                 # a second, stronger CPU number (not the reference's shape), for orientation
                 out["cpu_baseline_openmp"] = cpu_baseline_openmp(per_gpu, args.cell, args.eyesight, speed, workload=wl)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        leg["line"] = out
+    return leg
+
+
+def valu_ceiling():
+    """Measured VALU issue rates of the leased chip (tools/valu_ceiling.hip, run by tools/rocprof_passes.sh):
+    the newest profiles/rNN/valu_ceiling.json, or None."""
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "valu_ceiling.json")) as f:
+                c = json.load(f)
+            c["source"] = f"profiles/{rnd}/valu_ceiling.json"
+            return c
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 if __name__ == "__main__":

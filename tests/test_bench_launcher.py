@@ -1,0 +1,82 @@
+"""bench.py --gpus N: the rank launcher and its guards ("Next" item 1).
+
+CPU tests: the launcher starts `torch.distributed.run` as a child before torch is imported, and a
+rank refuses a WORLD_SIZE that differs from --gpus.  GPU test: `python bench.py --gpus 2` as a plain
+command (ranks sharing the one GPU of the test box over gloo) prints "n_gpus": 2.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks(tmp_path):
+    """--gpus 3 with no WORLD_SIZE: three ranks run (each fails here for want of a GPU, with the
+    engine's message, which proves they were started and parsed --gpus) and the exit code is theirs."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "1", "--warmup", "0", "--agents", "1000",
+                        "--no-cpu-baseline"], env=_env(CS_BENCH_BACKEND="gloo"), capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    # every rank got as far as the device check: world size matched --gpus
+    assert err.count("bench.py needs an MI355X") >= 1, err[-2000:]
+    assert "WORLD_SIZE=" not in err, err[-2000:]
+
+
+def test_a_rank_refuses_a_world_size_that_is_not_gpus():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "1"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 1 but WORLD_SIZE=2" in p.stderr
+
+
+def test_launcher_is_a_no_op_under_a_launcher(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+
+    class A:
+        gpus = 4
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.launch_ranks_if_needed(A()) is None  # returns instead of spawning
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_as_a_plain_command():
+    """The driver's command shape without its launcher: two ranks (gloo transport, one shared GPU),
+    strong scaling = 200k agents in all, the weak-scaled leg beside it."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "200000", "--steps", "10", "--warmup", "3",
+                        "--clock-warmup", "5", "--no-cpu-baseline"], env=_env(CS_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    assert line["scaling"] == "strong"
+    assert line["config"]["agents_total"] == 200000 and line["config"]["agents_per_gpu"] == 100000
+    assert line["config"]["ranks_in_comm"] == 2
+    assert line["weak_scaled"]["agents_total"] == 400000
+    assert line["value"] > 0 and line["weak_scaled"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_nccl_ranks_may_not_share_a_device():
+    """On the nccl backend two ranks on a one-GPU box must fail loudly, not land on one device."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "20000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "visible GPU" in (p.stderr + p.stdout)
