@@ -23,6 +23,10 @@ HIPCC_FLAGS = [
     # measured on the step kernel (3 runs each, 1M agents): 168.9 -> 164.4 us; scheduling only,
     # no effect on the arithmetic
     "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-fno-unroll-loops",
+    # no SLP vectorisation: it packs adjacent f32 operations into v_pk_mul / v_pk_fma / v_pk_add, which issue at
+    # half the rate of the plain forms on MI355X (tools/valu_ceiling.hip: 2 FMAs per 4.7 clocks against 2.3 each)
+    # and cost registers: the step kernel 145.9 -> 141.1 us, 128 -> 119 VGPRs, scratch 32 -> 0 B (round 3)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-value",
 ]
 

@@ -39,6 +39,9 @@
 #define CS_INVALID_CELL 0xFFFFFFFFu
 #define CS_MAX_GROUPS 65535u  // the group index travels in 16 bits of `meta`
 #define CS_SPAWN_OCCUPANCY_RADIUS 0.4  // hard-coded in the reference, lib.rs:212-214
+// Device ids are below 2^31 (`usize` in the reference): the tiled kernel reads "the neighbour's id is larger"
+// (right_of_way_vel, zanlungo.rs:173-198 with priority = id) off the sign of a 32-bit difference.
+#define CS_ID_LIMIT 0x7FFFFFFFull
 
 #include "cs_device_types.hip.inc"
 #include "cs_kernels_sort.hip.inc"
@@ -279,7 +282,11 @@ uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
   hipSetDevice(e->device);
   Counters c;
   if (e->read_counters(&c)) return 0;
-  return which == CS_STAT_WINDOWS_OFF_LDS ? c.n_win_off_lds : which == CS_STAT_WINDOWS_CHUNKED ? c.n_win_chunked : 0;
+  switch (which) {
+    case CS_STAT_WINDOWS_OFF_LDS: return c.n_win_off_lds;
+    case CS_STAT_WINDOWS_CHUNKED: return c.n_win_chunked;
+    default: return 0;
+  }
 }
 
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {

@@ -4,5 +4,5 @@
 name=$1; shift
 mkdir -p /root/repo/rmf_crowdsim_amd/lib/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -mllvm -amdgpu-sched-strategy=iterative-ilp -fno-unroll-loops -w "$@" \
+  -mllvm -amdgpu-sched-strategy=iterative-ilp -fno-unroll-loops -fno-slp-vectorize -w "$@" \
   -I /root/repo/include -o /root/repo/rmf_crowdsim_amd/lib/variants/$name.so /root/repo/rmf_crowdsim_amd/csrc/crowdstep_hip.hip && echo built $name
