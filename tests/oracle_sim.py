@@ -16,10 +16,14 @@ def load_oracle(kind="f64"):
     if kind in _libs:
         return _libs[kind]
     name = "libcrowdstep_oracle.so" if kind == "f64" else "libcrowdstep_oracle_f32.so"
+    target = []
+    if kind == "f64" and os.environ.get("CS_ORACLE_SANITIZED") == "1":
+        # the ASan + UBSan build (make -C oracle asan): this process must have libasan preloaded
+        name, target = "libcrowdstep_oracle_asan.so", ["asan"]
     path = os.path.join(ORACLE_DIR, "_build", name)
     src = os.path.join(ORACLE_DIR, "crowdstep_oracle.cpp")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+        subprocess.run(["make", "-C", ORACLE_DIR] + target, check=True, capture_output=True)
     lib = _abi.bind(ctypes.CDLL(path))
     lib.oracle_time_to_collision.restype = ctypes.c_double
     lib.oracle_time_to_collision.argtypes = [ctypes.c_double] * 5

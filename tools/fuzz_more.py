@@ -104,14 +104,13 @@ if which == "sinks":  # the source-sink / route-follower scenes (engine, oracle 
                 except AssertionError as err:
                     if "[None, None, (" in str(err) and "Index out of bounds" in str(err):
                         # the mesh alone failed: a tile's grid edges are strict, the single engine clamps below the
-                        # grid and ALIASES above the row stride like the reference; look at it
-                        # with tools/dbg_mesh_sinks.py if in doubt (seed 177: a walker leaving through y = 80)
+                        # grid and ALIASES above the row stride like the reference
+                        # (seed 177: a walker leaving through y = 80)
                         print(f"  seed {seed}: only the mesh failed with 'Index out of bounds' ({fn.__name__}): strict tile edges?")
                         continue
                     if str(err).startswith("[None, (") and str(err).rstrip().endswith("None]"):
                         # the f64 oracle alone left the grid: the reference's own f64 artifacts (|rel_vel|^2 underflow
                         # reads as "colliding now"), which f32 cannot reproduce
-                        # (tools/chk_engine_vs_oracle_fail.py SEED shows who flew off)
                         print(f"  seed {seed}: only the f64 oracle failed ({fn.__name__}): the reference's f64 artifact?")
                         continue
                     if split == "1" and "halo band" in str(err):  # a NaN agent (the model blew up) binned to cell 0:
