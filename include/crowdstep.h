@@ -316,6 +316,11 @@ uint64_t cs_device_bytes(cs_engine*);
  * Diagnostics of the engine's own work decomposition; the reference has no counterpart. */
 #define CS_STAT_WINDOWS_OFF_LDS 0u
 #define CS_STAT_WINDOWS_CHUNKED 1u
+/* halo exchanges a tile engine with CS_CFG_TILE_OVERLAP issued AHEAD (cs_tile_step_rccl: on its second stream, behind the
+ * border windows' launch, for the next step) and how many of those the next step could use (the others were made void
+ * by a change of the agents in between) */
+#define CS_STAT_EXCHANGES_AHEAD 2u
+#define CS_STAT_EXCHANGES_AHEAD_USED 3u
 uint64_t cs_kernel_stat(cs_engine*, uint32_t which);
 
 /* ---- measurement (bench.py / rocprof cross-check) ---------------------- */

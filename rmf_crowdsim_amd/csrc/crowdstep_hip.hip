@@ -70,6 +70,7 @@ void cs_destroy(cs_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->aux_stream) hipStreamSynchronize(e->aux_stream);  // (an exchange made ahead may still be in flight there)
   if (e->rccl_comm && e->rccl_comm_owned && rccl_api::api().comm_destroy) rccl_api::api().comm_destroy(e->rccl_comm);
   e->free_arrays(e->buf[0]);
   e->free_arrays(e->buf[1]);
@@ -172,6 +173,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_ASYNC")) e->kTileAsync = (uint32_t)std::max(1, atoi(v));
   if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_TILE_WINDOWS_CAP")) e->tile_windows_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
   const bool is_tile = cfg && (cfg->tile_cx1 | cfg->tile_cy1);
@@ -280,6 +282,8 @@ uint64_t cs_device_bytes(cs_engine* e) { return e->device_bytes(); }
 
 uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
   hipSetDevice(e->device);
+  if (which == CS_STAT_EXCHANGES_AHEAD) return e->n_exchanges_ahead;
+  if (which == CS_STAT_EXCHANGES_AHEAD_USED) return e->n_exchanges_ahead_used;
   Counters c;
   if (e->read_counters(&c)) return 0;
   switch (which) {
@@ -884,6 +888,7 @@ int cs_halo_exchange_rccl(cs_engine* e, int32_t axis) {
     // the previous cs_tile_step_rccl already exchanged this state's halo on its second stream,
     // behind the border windows' launch: wait for it (in stream order) instead of sending again
     e->exchanged_ahead = false;
+    e->n_exchanges_ahead_used += 1;
     return hipStreamWaitEvent(e->stream, e->ev_xchg, 0) == hipSuccess ? 0 : 90;
   }
   if (e->aux_stream && e->ev_xchg)  // (an exchange ahead that a later change of the agents made void)
@@ -944,8 +949,10 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
   if (int rc = e->halo_unpack_all()) return rc;
   if (int rc = e->upload_sinks()) return rc;
   if (int rc = e->upload_groups()) return rc;
-  if (e->n_live_sinks > 0) {
-    if (e->record_events || e->any_callback_hlp) {
+  // (gated on the sink SLOTS, which every rank counts alike and which never shrink: a rank that takes the split
+  // calls instead all-reduces under the same condition, DistributedTiles.step)
+  if (!e->sinks.empty()) {
+    if (e->n_live_sinks > 0 && (e->record_events || e->any_callback_hlp)) {
       e->error = "cs_tile_step_rccl: listeners and host planners need the split calls (cs_spawn_probe / cs_spawn_commit)";
       return 3;
     }
@@ -972,6 +979,7 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
     if (int rc2 = halo_exchange_rccl_on(e, -1, e->aux_stream)) return rc2;
     HIP_OK_E(e, hipEventRecord(e->ev_xchg, e->aux_stream));
     e->exchanged_ahead = true;
+    e->n_exchanges_ahead += 1;
   }
   return rc;
 }

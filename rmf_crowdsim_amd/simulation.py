@@ -680,7 +680,8 @@ class Simulation:
 
     def kernel_stat(self, which):
         """Diagnostics of the tiled kernel's work decomposition since creation (cs_kernel_stat):
-        0 = windows that left the LDS path, 1 = windows walked in chunks."""
+        0 = windows that left the LDS path, 1 = windows walked in chunks; 2 / 3 = halo exchanges a tile with
+        CS_CFG_TILE_OVERLAP issued ahead / could use."""
         return int(self._lib.cs_kernel_stat(self._engine, int(which)))
 
     @property

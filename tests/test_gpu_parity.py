@@ -386,6 +386,21 @@ def test_band_windows_stay_within_the_launch_when_the_staging_bound_cuts_them(st
     assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
 
 
+@pytest.mark.parametrize("report", [True, False])
+def test_windows_beyond_the_launch_fail_the_step_loudly(report, monkeypatch):
+    """The step kernel's launch and the window list are sized by a bound on what the builder can produce
+    (advisor finding, round 2: nothing checked it).  CS_TILE_WINDOWS_CAP shrinks the launch below what the
+    scene needs: the builder and the kernel count the windows they could not list / run, and the engine
+    refuses to go on (their agents were not stepped) instead of returning a crowd that silently lost them."""
+    monkeypatch.setenv("CS_TILE_WINDOWS_CAP", "40")
+    s, _ = _crowd(Simulation, 30000, 2.0, 2.0, scenes.CREEP_SPEED, flags=2)
+    with pytest.raises(RuntimeError, match="more band windows than the step kernel's launch"):
+        s.step(0.05, report=report)
+        s.synchronize()
+    with pytest.raises(RuntimeError):  # poisoned for good
+        s.step(0.05)
+
+
 @pytest.mark.parametrize("scene", ["walking edge", "cell 4 m", "hotspots", "cell 1 m, eyesight 2 m"])
 def test_every_window_stays_on_the_lds_path(scene):
     """The window builder bounds a window by what it STAGES (its own rows and columns plus the ghost

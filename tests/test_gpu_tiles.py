@@ -474,7 +474,45 @@ def _rank_nccl_single(port, out_path):
                                             for d in (XLO, XHI))
                 sent = [int(bufs[d][0][:4].cpu().numpy().view("<u4")[0]) for d in (XLO, XHI)]
                 recv_bytes[transport] = recv_bytes[transport] and min(sent) > 20
+        # CS_CFG_TILE_OVERLAP with REAL send buffers and peers (advisor finding, round 2: with a 1 x 1 mesh the step
+        # kernel never packs, so the exchange made AHEAD on the second stream, its event, and what voids it were
+        # never reached).  A tile in the middle of the grid whose XLO / XHI peers are this rank itself; the crowd
+        # keeps clear of the bands along those edges, so the buffers travel with a count of zero and the overlapped
+        # schedule must give the bits of the plain one, also across an add_agents and a remove_agents between steps
+        # (both void the exchange made ahead: it is then repeated on the engine's stream).
+        from rmf_crowdsim_amd import _abi
+
+        def middle_tile(flags):
+            with torch.cuda.stream(side):
+                sim = Simulation(LocationHash2D(**grid), device=0, stream=side.cuda_stream, tile=(10, 20, 0, 30),
+                                 halo_cells=1, flags=flags)
+                cap = 1024
+                keep = {d: (torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda"),
+                            torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda")) for d in (XLO, XHI)}
+                for d, (s_, r_) in keep.items():
+                    sim.halo_set_buffers(d, s_.data_ptr(), r_.data_ptr(), cap)
+                sim.rccl_comm_init(1, 0, sim.rccl_unique_id())
+                sim.halo_set_peers([0, 0, -1, -1, -1, -1, -1, -1])
+                lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+                sim.add_agents(scenes.jittered_lattice(900, 0.63, (25.0, 6.0), 0.2, 3, columns=16), StubHighLevelPlan((0.0, 0.3)), lp, 2.0)
+                for k in range(60):
+                    sim.tile_step_rccl(0.05)
+                    if k == 20:
+                        sim.add_agents([(29.0 + 0.1 * q, 50.0) for q in range(8)], StubHighLevelPlan((0.0, -0.3)), lp, 2.0)
+                    if k == 40:
+                        sim.remove_agents(3)
+                side.synchronize()
+                out = sim.read_agents()
+                stats = (sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD), sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD_USED))
+                del sim
+            return out, stats
+        plain, plain_stats = middle_tile(0)
+        ahead, ahead_stats = middle_tile(_abi.CS_CFG_TILE_OVERLAP)
+        print("exchanges ahead / used:", ahead_stats, "plain:", plain_stats, "agents", len(plain), flush=True)
+        overlap_ahead = (len(plain) == 907 and plain.tobytes() == ahead.tobytes() and plain_stats == (0, 0) and
+                         ahead_stats[0] >= 50 and ahead_stats[0] - ahead_stats[1] in (2, 3))
         checks = {"stream_order": ok, "mesh_engine_vs_torch": results["engine"].tobytes() == results["torch"].tobytes(),
+                  "overlap_exchange_ahead": overlap_ahead,
                   "overlap_streams": results["overlap"].tobytes() == results["engine"].tobytes(),
                   "self_exchange_engine": recv_bytes["engine"], "self_exchange_torch": recv_bytes["torch"]}
         print("rccl checks:", checks, "records sent", sent, flush=True)
