@@ -132,9 +132,41 @@ struct RouteFollower : HighLevelPlanner {
   }
 };
 
-struct LocalPlanner {  // local_planner.rs:7-18: only the shipped planners run on the device
+// local_planner.rs:7-18.  The shipped planners (below) run on the device; any other subclass is host code:
+// override get_desired_velocity and the engine evaluates it every step through its batched callback
+// (cs_register_lp_callback: the slow path), with the agent and its neighbours as they were at the start of the step.
+struct LocalPlanner {
   virtual ~LocalPlanner() = default;
-  virtual uint32_t register_with(cs_engine*) = 0;
+  virtual Vec2f get_desired_velocity(const Agent& agent, const std::vector<Agent>& nearby_agents,
+                                     Vec2f recommended_velocity) const {
+    (void)agent; (void)nearby_agents;
+    return recommended_velocity;
+  }
+  virtual uint32_t register_with(cs_engine* e) {
+    return cs_register_lp_callback(
+        e,
+        [](void* u, size_t n, const cs_lp_agent* agents, const double* rec, const uint64_t* nb_begin,
+           const cs_lp_agent* nb, double* out) {
+          const auto view = [](const cs_lp_agent& r) {
+            Agent a{};
+            a.agent_id = r.agent_id;
+            a.position = {r.x, r.y};
+            a.velocity = {r.vx, r.vy};
+            a.next_waypoint = r.next_waypoint;
+            a.eyesight_range = r.eyesight_range;
+            return a;
+          };
+          const LocalPlanner* self = static_cast<const LocalPlanner*>(u);
+          for (size_t k = 0; k < n; ++k) {
+            std::vector<Agent> nearby;
+            for (uint64_t q = nb_begin[k]; q < nb_begin[k + 1]; ++q) nearby.push_back(view(nb[q]));
+            const Vec2f v = self->get_desired_velocity(view(agents[k]), nearby, Vec2f{rec[2 * k], rec[2 * k + 1]});
+            out[2 * k] = v.x;
+            out[2 * k + 1] = v.y;
+          }
+        },
+        this);
+  }
 };
 struct NoLocalPlan : LocalPlanner {  // no_local_plan.rs:7-18
   uint32_t register_with(cs_engine* e) override { return cs_register_no_local_plan(e); }

@@ -160,6 +160,31 @@ typedef struct cs_hlp_desc {
 enum { CS_GEN_MONOTONIC = 0, CS_GEN_POISSON_SEEDED = 1, CS_GEN_CALLBACK = 2 };
 typedef size_t (*cs_generator_fn)(void* user, double dt_seconds);
 
+/* A LocalPlanner that is host code: trait LocalPlanner, local_planners/local_planner.rs:7-18, called at
+ * lib.rs:276-291.  THE SLOW PATH: the two planners the reference ships run on the device
+ * (cs_register_zanlungo / cs_register_no_local_plan); any other one is evaluated on the host, batched per planner
+ * and step.  cs_lp_agent is the reference's Agent (lib.rs:47-65) as `step` maintains it (orientation and
+ * angular_vel are never written after creation, lib.rs:138,141).  The callback gets, for every agent of the
+ * planner that this engine steps, in ascending id:
+ *   agents[k]               the agent as it was at the start of the step, preferred_vel = the velocity its
+ *                           high-level planner recommends (the clone of lib.rs:261-271)
+ *   recommended_xy[2k..]    that velocity again: the third argument of get_desired_velocity
+ *   neighbours[nb_begin[k] .. nb_begin[k + 1])   the agents within agents[k].eyesight_range of it (strict <,
+ *                           itself excluded: lib.rs:279-287), start-of-step state, preferred_vel = (0, 0) as in the
+ *                           reference, in the canonical order of the step (cells
+ *                           x-major / y-minor, ascending id inside a cell)
+ * and writes the agent's new velocity to out_velocity_xy[2k..]. */
+typedef struct cs_lp_agent {
+  uint64_t agent_id;
+  double x, y;
+  double vx, vy;
+  double preferred_vx, preferred_vy;
+  double eyesight_range;
+  uint64_t next_waypoint;
+} cs_lp_agent;
+typedef void (*cs_lp_batch_fn)(void* user, size_t n_agents, const cs_lp_agent* agents, const double* recommended_xy,
+                               const uint64_t* nb_begin, const cs_lp_agent* neighbours, double* out_velocity_xy);
+
 /* struct SourceSink                              source_sink/source_sink.rs:36-60 */
 typedef struct cs_source_sink_desc {
   double source_x, source_y;
@@ -221,6 +246,8 @@ const char* cs_backend_name(const cs_engine*);
 /* ---- planners as data -------------------------------------------------- */
 uint32_t cs_register_zanlungo(cs_engine*, const cs_zanlungo_params*); /* zanlungo.rs:31 */
 uint32_t cs_register_no_local_plan(cs_engine*);           /* no_local_plan.rs:7-18 */
+/* any other `impl LocalPlanner`: evaluated on the host (see cs_lp_batch_fn)   local_planner.rs:7-18 */
+uint32_t cs_register_lp_callback(cs_engine*, cs_lp_batch_fn fn, void* user);
 uint32_t cs_register_hlp(cs_engine*, const cs_hlp_desc*); /* highlevel_planners.rs:8 */
 
 /* ---- population -------------------------------------------------------- */

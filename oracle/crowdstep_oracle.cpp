@@ -278,6 +278,38 @@ struct NoLocalPlan : LocalPlanner {
   }
 };
 
+// any other `impl LocalPlanner` (local_planner.rs:7-18): host code behind the C ABI's batch callback, called
+// here the way the reference calls a planner: once per agent, with its neighbours' old states (lib.rs:276-291)
+struct CallbackLocalPlanner : LocalPlanner {
+  cs_lp_batch_fn fn = nullptr;
+  void* user = nullptr;
+  static cs_lp_agent record(const Agent& a, bool with_preferred) {
+    cs_lp_agent r;
+    r.agent_id = a.agent_id;
+    r.x = (double)a.position.x;
+    r.y = (double)a.position.y;
+    r.vx = (double)a.velocity.x;
+    r.vy = (double)a.velocity.y;
+    r.preferred_vx = with_preferred ? (double)a.preferred_vel.x : 0.0;
+    r.preferred_vy = with_preferred ? (double)a.preferred_vel.y : 0.0;
+    r.eyesight_range = (double)a.eyesight_range;
+    r.next_waypoint = a.next_waypoint;
+    return r;
+  }
+  V2 get_desired_velocity(const Agent& agent, const std::vector<Agent>& nearby, V2 recommended,
+                          bool*) const override {
+    const cs_lp_agent me = record(agent, true);
+    std::vector<cs_lp_agent> nb;
+    for (const Agent& a : nearby) nb.push_back(record(a, true));  // (a neighbour's preferred_vel is (0,0): lib.rs:140)
+    const uint64_t begin[2] = {0, (uint64_t)nb.size()};
+    if (nb.empty()) nb.emplace_back();
+    const double rec[2] = {(double)recommended.x, (double)recommended.y};
+    double out[2] = {0.0, 0.0};
+    fn(user, 1, &me, rec, begin, nb.data(), out);
+    return V2{(Real)out[0], (Real)out[1]};
+  }
+};
+
 // zanlungo.rs:9-218
 struct Zanlungo : LocalPlanner {
   Real agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass, agent_radius;
@@ -839,6 +871,17 @@ uint32_t cs_register_zanlungo(cs_engine* e, const cs_zanlungo_params* p) {
 }
 uint32_t cs_register_no_local_plan(cs_engine* e) {
   e->lps.push_back(std::make_shared<NoLocalPlan>());
+  return (uint32_t)e->lps.size() - 1;
+}
+uint32_t cs_register_lp_callback(cs_engine* e, cs_lp_batch_fn fn, void* user) {
+  if (!fn) {
+    e->error = "cs_register_lp_callback: the planner's function is null";
+    return UINT32_MAX;
+  }
+  auto p = std::make_shared<CallbackLocalPlanner>();
+  p->fn = fn;
+  p->user = user;
+  e->lps.push_back(p);
   return (uint32_t)e->lps.size() - 1;
 }
 uint32_t cs_register_hlp(cs_engine* e, const cs_hlp_desc* d) {

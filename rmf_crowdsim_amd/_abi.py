@@ -58,6 +58,16 @@ HlpRemoveFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)
 GeneratorFn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_double)
 
 
+class LpAgent(C.Structure):
+    _fields_ = [("agent_id", C.c_uint64), ("x", C.c_double), ("y", C.c_double), ("vx", C.c_double),
+                ("vy", C.c_double), ("preferred_vx", C.c_double), ("preferred_vy", C.c_double),
+                ("eyesight_range", C.c_double), ("next_waypoint", C.c_uint64)]
+
+
+LpBatchFn = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.POINTER(LpAgent), C.POINTER(C.c_double),
+                        C.POINTER(C.c_uint64), C.POINTER(LpAgent), C.POINTER(C.c_double))
+
+
 RoutePlanFn = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
                           C.POINTER(C.c_double), C.c_size_t)
 
@@ -122,6 +132,7 @@ SYMBOLS = {
     "cs_backend_name": (C.c_char_p, [C.c_void_p]),
     "cs_register_zanlungo": (C.c_uint32, [C.c_void_p, C.POINTER(ZanlungoParams)]),
     "cs_register_no_local_plan": (C.c_uint32, [C.c_void_p]),
+    "cs_register_lp_callback": (C.c_uint32, [C.c_void_p, LpBatchFn, C.c_void_p]),
     "cs_register_hlp": (C.c_uint32, [C.c_void_p, C.POINTER(HlpDesc)]),
     "cs_add_agents": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint32,
                                 C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]),

@@ -197,6 +197,7 @@ const char* cs_backend_name(const cs_engine* e) { return e ? e->backend.c_str() 
 uint32_t cs_register_zanlungo(cs_engine* e, const cs_zanlungo_params* p) {
   e->lp_params.push_back(*p);
   e->lp_kinds.push_back(1u);
+  e->lp_callbacks.emplace_back();
   return (uint32_t)e->lp_kinds.size() - 1;
 }
 uint32_t cs_register_no_local_plan(cs_engine* e) {
@@ -206,6 +207,24 @@ uint32_t cs_register_no_local_plan(cs_engine* e) {
   z.force_distance = 1.0;
   e->lp_params.push_back(z);
   e->lp_kinds.push_back(0u);
+  e->lp_callbacks.emplace_back();
+  return (uint32_t)e->lp_kinds.size() - 1;
+}
+uint32_t cs_register_lp_callback(cs_engine* e, cs_lp_batch_fn fn, void* user) {
+  if (!fn) {
+    e->error = "cs_register_lp_callback: the planner's function is null";
+    return UINT32_MAX;
+  }
+  cs_zanlungo_params z;
+  std::memset(&z, 0, sizeof z);
+  z.agent_mass = 1.0;
+  z.force_distance = 1.0;
+  e->lp_params.push_back(z);
+  e->lp_kinds.push_back(2u);
+  cs_engine::LpCallback cb;
+  cb.fn = fn;
+  cb.user = user;
+  e->lp_callbacks.push_back(cb);
   return (uint32_t)e->lp_kinds.size() - 1;
 }
 uint32_t cs_register_hlp(cs_engine* e, const cs_hlp_desc* d) {
@@ -477,7 +496,7 @@ static size_t radius_query(cs_engine* e, double radius, double x, double y, std:
 // against the local grid and reports owned agents only.
 static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const double* radius, size_t cap,
                               std::vector<uint32_t>* ids, std::vector<float>* d2, std::vector<uint32_t>* cells,
-                              std::vector<uint32_t>* counts, bool every_alias) {
+                              std::vector<uint32_t>* counts, bool every_alias, bool with_ghosts = false) {
   counts->assign(n, 0u);
   ids->assign(n * cap, 0u);
   d2->assign(n * cap, 0.0f);
@@ -529,7 +548,7 @@ static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const do
   if (ok) {
     ok = hipMemcpyAsync(d_q, q.data(), n * sizeof(QueryDev), hipMemcpyHostToDevice, e->stream) == hipSuccess;
     hipLaunchKernelGGL(k_query_radius_batch, dim3((uint32_t)n), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
-                       e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, (e->tile && e->ghosts_present) ? 1u : 0u, d_ids,
+                       e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, (e->tile && e->ghosts_present && !with_ghosts) ? 1u : 0u, d_ids,
                        d_d2, d_cells, (uint32_t)cap, d_cnt);
     ok = ok && hipMemcpyAsync(counts->data(), d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
          hipMemcpyAsync(ids->data(), d_ids, n * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
@@ -559,6 +578,106 @@ int cs_query_radius_batch(cs_engine* e, size_t n, const double* xy, const double
       if (out_d2) out_d2[k * cap_per_query + i] = d2[k * cap_per_query + i];
       if (out_cells) out_cells[k * cap_per_query + i] = cells[k * cap_per_query + i];
     }
+  }
+  return 0;
+}
+
+// A step's turn of the host LocalPlanners (cs_register_lp_callback; local_planner.rs:7-18 called at lib.rs:276-291).
+// Runs inside cs_step on the SORTED start-of-step state, after the spawn phase and the high-level planners'
+// callbacks: (1) k_lp_recommended writes the velocity the high-level planner recommends for every agent of such a
+// planner, (2) the state comes to the host, (3) the neighbours of those agents come from the device index through
+// the batch radius query (cells x-major / y-minor, ascending id in a cell: the step's canonical order; the agent
+// itself dropped, lib.rs:284; a tile's ghosts included), (4) every planner is called once with its agents in
+// ascending id, (5) the answers go back by slot and the step kernels read them instead of evaluating a planner.
+static int lp_callbacks_eval(cs_engine* e, const StepParams& P, const EpilogueCtx* Ep) {
+  const uint32_t n = e->n_slots;
+  hipLaunchKernelGGL(k_lp_recommended, dim3((n + 255u) / 256u), dim3(256), 0, e->stream, P, e->view(e->cur), Ep, e->pref,
+                     e->lp_vel);
+  cs_engine::HostState h;
+  if (int rc = e->download(&h)) return rc;  // (synchronises the stream)
+  std::vector<float2> rec(n);
+  if (hipMemcpy(rec.data(), e->lp_vel, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) {
+    e->error = "HIP error in a host local planner's turn";
+    return 90;
+  }
+  // the agents of host planners that THIS engine steps (a tile: the owned ones), by planner, ascending id
+  std::vector<std::vector<uint32_t>> by_lp(e->lp_kinds.size());
+  for (uint32_t i = 0; i < n; ++i) {
+    if (h.cell[i] == CS_INVALID_CELL) continue;
+    const auto& g = e->groups[h.meta[i] & 0xFFFFu];
+    if (e->lp_kinds[g.lp] != 2u) continue;
+    if (e->tile) {
+      const uint32_t cx = h.cell[i] / (uint32_t)e->nx, cy = h.cell[i] - cx * (uint32_t)e->nx;
+      if (cx < e->gdev.own_x0 || cx >= e->gdev.own_x1 || cy < e->gdev.own_y0 || cy >= e->gdev.own_y1) continue;
+    }
+    by_lp[g.lp].push_back(i);
+  }
+  std::vector<uint32_t> slot_of_id;  // id -> slot + 1, for the neighbours' state
+  {
+    uint32_t max_id = 0;
+    for (uint32_t i = 0; i < n; ++i)
+      if (h.cell[i] != CS_INVALID_CELL) max_id = std::max(max_id, h.id[i]);
+    slot_of_id.assign((size_t)max_id + 1u, 0u);
+    for (uint32_t i = 0; i < n; ++i)
+      if (h.cell[i] != CS_INVALID_CELL) slot_of_id[h.id[i]] = i + 1u;
+  }
+  auto agent_of = [&](uint32_t i, double pvx, double pvy) {
+    cs_lp_agent a;
+    a.agent_id = h.id[i];
+    e->to_global(h.cell[i], h.off[i].x, h.off[i].y, &a.x, &a.y);
+    a.vx = h.vel[i].x;
+    a.vy = h.vel[i].y;
+    a.preferred_vx = pvx;
+    a.preferred_vy = pvy;
+    a.eyesight_range = e->groups[h.meta[i] & 0xFFFFu].eyesight;
+    a.next_waypoint = h.meta[i] >> 16;
+    return a;
+  };
+  std::vector<float2> out(n, make_float2(0.f, 0.f));
+  for (size_t lp = 0; lp < by_lp.size(); ++lp) {
+    std::vector<uint32_t>& slots = by_lp[lp];
+    if (slots.empty()) continue;
+    std::sort(slots.begin(), slots.end(), [&](uint32_t a, uint32_t b) { return h.id[a] < h.id[b]; });
+    const size_t m = slots.size();
+    std::vector<cs_lp_agent> agents(m);
+    std::vector<double> xy(2 * m), radius(m), recommended(2 * m), answer(2 * m, 0.0);
+    for (size_t k = 0; k < m; ++k) {
+      const uint32_t i = slots[k];
+      agents[k] = agent_of(i, rec[i].x, rec[i].y);
+      xy[2 * k] = agents[k].x;
+      xy[2 * k + 1] = agents[k].y;
+      radius[k] = agents[k].eyesight_range;
+      recommended[2 * k] = rec[i].x;
+      recommended[2 * k + 1] = rec[i].y;
+    }
+    std::vector<uint32_t> ids, cells, counts;
+    std::vector<float> d2;
+    size_t cap = 64;
+    for (;;) {  // (a crowd denser than the buffer: once more with room for the largest answer)
+      if (int rc = radius_query_batch(e, m, xy.data(), radius.data(), cap, &ids, &d2, &cells, &counts, true, true)) return rc;
+      const uint32_t most = counts.empty() ? 0u : *std::max_element(counts.begin(), counts.end());
+      if (most <= cap) break;
+      cap = (size_t)most + 16;
+    }
+    std::vector<uint64_t> nb_begin(m + 1, 0);
+    std::vector<cs_lp_agent> neighbours;
+    for (size_t k = 0; k < m; ++k) {
+      for (uint32_t q = 0; q < counts[k]; ++q) {
+        const uint32_t id = ids[k * cap + q];
+        if (id == agents[k].agent_id || id >= slot_of_id.size() || !slot_of_id[id]) continue;  // itself: lib.rs:284
+        neighbours.push_back(agent_of(slot_of_id[id] - 1u, 0.0, 0.0));
+      }
+      nb_begin[k + 1] = neighbours.size();
+    }
+    if (neighbours.empty()) neighbours.emplace_back();  // (a valid pointer for an empty list)
+    e->lp_callbacks[lp].fn(e->lp_callbacks[lp].user, m, agents.data(), recommended.data(), nb_begin.data(),
+                           neighbours.data(), answer.data());
+    for (size_t k = 0; k < m; ++k) out[slots[k]] = make_float2((float)answer[2 * k], (float)answer[2 * k + 1]);
+  }
+  if (hipMemcpyAsync(e->lp_vel, out.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess) {  // (`out` leaves scope)
+    e->error = "HIP error in a host local planner's turn";
+    return 90;
   }
   return 0;
 }

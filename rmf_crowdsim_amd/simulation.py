@@ -40,6 +40,7 @@ class Agent:
     eyesight_range: float
     orientation: float = 0.0   # never written after creation (lib.rs:138)
     angular_vel: float = 0.0   # never written after creation (lib.rs:141)
+    preferred_vel: object = None  # set on the clone a LocalPlanner sees (lib.rs:271); (0, 0) on its neighbours
 
 
 # ---- spatial index ---------------------------------------------------------
@@ -58,15 +59,56 @@ class LocationHash2D:
 
 # ---- local planners --------------------------------------------------------
 class LocalPlanner:
-    """trait LocalPlanner, local_planner.rs:7-18.  Only the two planners the
-    reference ships can run on the device; they are passed as data."""
+    """trait LocalPlanner, local_planner.rs:7-18.
+
+    The two planners the reference ships (Zanlungo, NoLocalPlan) run on the device; they are passed
+    as data.  Any other subclass is host code: override `get_desired_velocity`, and the engine
+    evaluates it through the batched callback each step (cs_register_lp_callback: the slow path of
+    SURVEY.md section 8b), with the agent and its neighbours as they were at the start of the step.
+    """
+
+    def get_desired_velocity(self, agent, nearby_agents, recommended_velocity):
+        """-> (vx, vy).  `agent.preferred_vel` is the recommended velocity too (lib.rs:271); the
+        neighbours' is (0, 0), as in the reference (lib.rs:140)."""
+        raise NotImplementedError
+
+    def add_agent(self, agent_id):       # local_planner.rs:14 (the reference never calls it: lib.rs:127-131 only
+        pass                             # stores the planner per agent)
+
+    def remove_agent(self, agent_id):    # local_planner.rs:16, called by remove_agents (lib.rs:181-184)
+        pass
+
+    _host_code = True  # the facade tells such a planner when one of its agents is removed
 
     def _register(self, lib, engine):
-        raise CrowdSimError("only Zanlungo and NoLocalPlan are device-evaluable local planners")
+        if type(self).get_desired_velocity is LocalPlanner.get_desired_velocity:
+            raise CrowdSimError("a LocalPlanner must be Zanlungo, NoLocalPlan or override get_desired_velocity")
+
+        def batch(_user, n, agents, recommended, nb_begin, neighbours, out):
+            def view(r, preferred):
+                a = Agent(int(r.agent_id), np.array([r.x, r.y]), np.array([r.vx, r.vy]), int(r.next_waypoint),
+                          float(r.eyesight_range))
+                a.preferred_vel = preferred
+                return a
+            for k in range(n):
+                rec = np.array([recommended[2 * k], recommended[2 * k + 1]])
+                me = view(agents[k], rec)
+                nearby = [view(neighbours[q], np.zeros(2)) for q in range(nb_begin[k], nb_begin[k + 1])]
+                vx, vy = self.get_desired_velocity(me, nearby, rec)
+                out[2 * k], out[2 * k + 1] = float(vx), float(vy)
+
+        fn = _abi.LpBatchFn(batch)
+        # one thunk per engine this planner is registered with; the engines hold the raw pointer
+        self._keepalive = getattr(self, "_keepalive", []) + [fn]
+        handle = lib.cs_register_lp_callback(engine, fn, None)
+        if handle == 0xFFFFFFFF:
+            raise CrowdSimError(lib.cs_last_error(engine).decode())
+        return handle
 
 
 class NoLocalPlan(LocalPlanner):
     """no_local_plan.rs:7-18: returns the recommended velocity unchanged."""
+    _host_code = False
 
     def _register(self, lib, engine):
         return lib.cs_register_no_local_plan(engine)
@@ -75,6 +117,8 @@ class NoLocalPlan(LocalPlanner):
 class Zanlungo(LocalPlanner):
     """Zanlungo::new(agent_scale, obstacle_scale, reaction_time, force_distance,
     agent_mass, agent_radius); zanlungo.rs:31-48."""
+
+    _host_code = False
 
     def __init__(self, agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass,
                  agent_radius):
@@ -299,6 +343,9 @@ class Simulation:
         self._lib.cs_event_recording(self._engine, 0)  # no listeners yet (lib.rs:88)
         self._planner_handles = {}
         self._planners_alive = []
+        self._host_lps = False  # some LocalPlanner is host code: its agents are tracked for remove_agent
+        self._host_lp_of_agent = {}
+        self._host_lp_of_sink = {}
         self._listeners = {}
         self._next_listener = 0
         self._source_sinks = {}
@@ -343,6 +390,13 @@ class Simulation:
             n = self._lib.cs_drain_events(self._engine, buf, len(buf))
             for i in range(n):
                 ev = buf[i]
+                if self._host_lps:  # LocalPlanner::remove_agent for agents of host planners (lib.rs:181-184)
+                    if ev.kind == _abi.CS_EVENT_SPAWNED and ev.source_sink in self._host_lp_of_sink:
+                        self._host_lp_of_agent[int(ev.id)] = self._host_lp_of_sink[ev.source_sink]
+                    elif ev.kind == _abi.CS_EVENT_DESTROYED:
+                        planner = self._host_lp_of_agent.pop(int(ev.id), None)
+                        if planner is not None:
+                            planner.remove_agent(int(ev.id))
                 for listener in self._listeners.values():
                     if ev.kind == _abi.CS_EVENT_SPAWNED:
                         listener.agent_spawned(np.array([ev.x, ev.y]), int(ev.id))
@@ -363,6 +417,11 @@ class Simulation:
             self._handle(high_level_planner), self._handle(local_planner),
             float(agent_eyesight_range), ids.ctypes.data_as(C.POINTER(C.c_uint64)))
         self._agents_cache = None
+        if getattr(local_planner, "_host_code", False):
+            self._host_lps = True
+            self._lib.cs_event_recording(self._engine, 1)
+            for i in ids[:n if rc == 0 else 0]:
+                self._host_lp_of_agent[int(i)] = local_planner
         self._dispatch_events()
         if rc != 0:
             raise self._err()
@@ -385,6 +444,10 @@ class Simulation:
         if handle == 0xFFFFFFFF:
             raise self._err()
         self._source_sinks[handle] = (source_sink, keep)
+        if getattr(source_sink.local_planner, "_host_code", False):
+            self._host_lps = True
+            self._host_lp_of_sink[handle] = source_sink.local_planner
+            self._lib.cs_event_recording(self._engine, 1)
         return handle
 
     def remove_source_sink(self, handle):
@@ -412,12 +475,12 @@ class Simulation:
         """lib.rs:195-383.  `dur`: seconds (float) or datetime.timedelta."""
         dt = dur.total_seconds() if isinstance(dur, datetime.timedelta) else float(dur)
         rep = _abi.StepReport()
-        need_report = report or bool(self._listeners)
+        need_report = report or bool(self._listeners) or self._host_lps
         rc = self._lib.cs_step(self._engine, dt, C.byref(rep) if need_report else None)
         self._agents_cache = None
         if need_report:
             self.last_report = rep.as_dict()
-        if self._listeners or rc != 0:
+        if self._listeners or self._host_lps or rc != 0:
             self._dispatch_events()
         if rc != 0:
             raise self._err()
@@ -555,8 +618,8 @@ class Simulation:
 
     @property
     def host_events_needed(self):
-        """True when spawn / waypoint / destroy events must reach the host (listeners)."""
-        return bool(self._listeners)
+        """True when spawn / waypoint / destroy events must reach the host (listeners, host local planners)."""
+        return bool(self._listeners) or self._host_lps
 
     # -- tiles (multi-GPU): halo hooks, see tiles.py --
     def halo_set_buffers(self, direction, send_ptr, recv_ptr, capacity_records):

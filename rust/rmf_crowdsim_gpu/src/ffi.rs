@@ -105,6 +105,22 @@ pub type cs_hlp_remove_fn = Option<unsafe extern "C" fn(user: *mut c_void, id: u
 pub type cs_route_plan_fn = Option<unsafe extern "C" fn(user: *mut c_void, start_x: f64, start_y: f64, goal_x: f64, goal_y: f64, out_xy: *mut f64, cap: usize) -> usize>;
 pub type cs_generator_fn = Option<unsafe extern "C" fn(user: *mut c_void, dt_seconds: f64) -> usize>;
 
+/// The reference's Agent (lib.rs:47-65) as a host LocalPlanner sees it (slow path, cs_register_lp_callback)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cs_lp_agent {
+    pub agent_id: u64,
+    pub x: f64,
+    pub y: f64,
+    pub vx: f64,
+    pub vy: f64,
+    pub preferred_vx: f64,
+    pub preferred_vy: f64,
+    pub eyesight_range: f64,
+    pub next_waypoint: u64,
+}
+pub type cs_lp_batch_fn = Option<unsafe extern "C" fn(user: *mut c_void, n_agents: usize, agents: *const cs_lp_agent, recommended_xy: *const f64, nb_begin: *const u64, neighbours: *const cs_lp_agent, out_velocity_xy: *mut f64)>;
+
 /// HighLevelPlanner as data, highlevel_planners.rs:8-16
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -208,6 +224,7 @@ extern "C" {
     pub fn cs_backend_name(e: *const cs_engine) -> *const c_char;
     pub fn cs_register_zanlungo(e: *mut cs_engine, p: *const cs_zanlungo_params) -> u32;
     pub fn cs_register_no_local_plan(e: *mut cs_engine) -> u32;
+    pub fn cs_register_lp_callback(e: *mut cs_engine, f: cs_lp_batch_fn, user: *mut c_void) -> u32;
     pub fn cs_register_hlp(e: *mut cs_engine, d: *const cs_hlp_desc) -> u32;
     pub fn cs_add_agents(e: *mut cs_engine, xy: *const f64, n: usize, hlp: u32, lp: u32, eyesight: f64, out_ids: *mut u64) -> c_int;
     pub fn cs_remove_agent(e: *mut cs_engine, id: u64) -> c_int;

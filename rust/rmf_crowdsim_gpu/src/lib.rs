@@ -88,6 +88,7 @@ pub struct Simulation<T: SpatialIndex> {
     lp_handles: HashMap<usize, u32>,
     // everything the engine holds raw pointers into stays alive as long as the engine
     keep_hlps: Vec<Box<Arc<Mutex<dyn HighLevelPlanner>>>>,
+    keep_lps: Vec<Box<Arc<Mutex<dyn LocalPlanner>>>>,
     keep_generators: Vec<Box<Arc<dyn CrowdGenerator>>>,
     keep_sinks: Vec<Arc<SourceSink>>,
     agents_view: bool,
@@ -117,6 +118,31 @@ unsafe extern "C" fn hlp_velocity_trampoline(user: *mut c_void, n: usize, ids: *
             }
             None => *out_some.add(i) = 0,
         }
+    }
+}
+
+/// cs_lp_batch_fn: `LocalPlanner::get_desired_velocity` for every agent of one host planner (lib.rs:276-291)
+unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents: usize, agents: *const ffi::cs_lp_agent,
+                                         recommended_xy: *const f64, nb_begin: *const u64,
+                                         neighbours: *const ffi::cs_lp_agent, out_velocity_xy: *mut f64) {
+    let planner = &*(user as *const Arc<Mutex<dyn LocalPlanner>>);
+    let p = planner.lock().unwrap();
+    let view = |r: &ffi::cs_lp_agent| Agent {
+        agent_id: r.agent_id as usize,
+        position: Point::new(r.x, r.y),
+        orientation: 0f64,
+        velocity: Vector2::new(r.vx, r.vy),
+        angular_vel: 0f64,
+        next_waypoint: r.next_waypoint as usize,
+        eyesight_range: r.eyesight_range,
+    };
+    for k in 0..n_agents {
+        let (b, e) = (*nb_begin.add(k) as usize, *nb_begin.add(k + 1) as usize);
+        let nearby: Vec<Agent> = (b..e).map(|q| view(&*neighbours.add(q))).collect();
+        let recommended = Vector2::new(*recommended_xy.add(2 * k), *recommended_xy.add(2 * k + 1));
+        let v = p.get_desired_velocity(&view(&*agents.add(k)), &nearby, recommended);
+        *out_velocity_xy.add(2 * k) = v.x;
+        *out_velocity_xy.add(2 * k + 1) = v.y;
     }
 }
 
@@ -185,6 +211,7 @@ impl<T: SpatialIndex> Simulation<T> {
             hlp_handles: HashMap::new(),
             lp_handles: HashMap::new(),
             keep_hlps: Vec::new(),
+            keep_lps: Vec::new(),
             keep_generators: Vec::new(),
             keep_sinks: Vec::new(),
             agents_view: true,
@@ -262,10 +289,17 @@ impl<T: SpatialIndex> Simulation<T> {
         let handle = match planner.lock().unwrap().device_form() {
             DeviceLocalPlan::NoLocalPlan => unsafe { ffi::cs_register_no_local_plan(self.engine) },
             DeviceLocalPlan::Zanlungo(params) => unsafe { ffi::cs_register_zanlungo(self.engine, &params) },
-            DeviceLocalPlan::Unsupported => {
-                return Err("only Zanlungo and NoLocalPlan are device-evaluable local planners".to_string())
+            DeviceLocalPlan::HostCallback => {
+                // the engine keeps `user`: a heap cell holding a clone of the Arc, alive as long as `self`
+                let cell = Box::new(planner.clone());
+                let user = &*cell as *const Arc<Mutex<dyn LocalPlanner>> as *mut c_void;
+                self.keep_lps.push(cell);
+                unsafe { ffi::cs_register_lp_callback(self.engine, Some(lp_batch_trampoline), user) }
             }
         };
+        if handle == u32::MAX {
+            return Err(self.last_error());
+        }
         self.lp_handles.insert(key, handle);
         Ok(handle)
     }

@@ -6,9 +6,9 @@ use crate::{Agent, AgentId, Vec2f};
 pub enum DeviceLocalPlan {
     NoLocalPlan,
     Zanlungo(ffi::cs_zanlungo_params),
-    /// a user-defined planner: it would need every neighbour of every agent on the host each
-    /// step; `add_agents` / `add_source_sink` return Err for it
-    Unsupported,
+    /// a user-defined planner (the default): host code, evaluated every step through the engine's batched
+    /// callback with each agent's neighbours (cs_register_lp_callback: the slow path)
+    HostCallback,
 }
 
 /// local_planners/local_planner.rs:7-18, plus `device_form`.
@@ -20,7 +20,7 @@ pub trait LocalPlanner {
     fn remove_agent(&mut self, _id: AgentId) {}
 
     fn device_form(&self) -> DeviceLocalPlan {
-        DeviceLocalPlan::Unsupported
+        DeviceLocalPlan::HostCallback
     }
 }
 

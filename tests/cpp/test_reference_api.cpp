@@ -108,12 +108,42 @@ static void test_snapshots() {
   }
 }
 
+// A LocalPlanner written by the user (local_planner.rs:7-18): host code, evaluated through the engine's batched
+// callback.  This one steers away from the mean position of whoever it sees; with one neighbour 1 m to the right
+// the answer is known in closed form.
+struct ShyPlanner : LocalPlanner {
+  mutable int calls = 0;
+  Vec2f get_desired_velocity(const Agent& agent, const std::vector<Agent>& nearby, Vec2f recommended) const override {
+    ++calls;
+    Vec2f w = recommended;
+    for (const Agent& other : nearby) {
+      w.x -= 0.5 * (other.position.x - agent.position.x);
+      w.y -= 0.5 * (other.position.y - agent.position.y);
+    }
+    return w;
+  }
+};
+
+static void test_user_local_planner() {
+  Simulation sim(LocationHash2D(100.0, 100.0, 2.0, Point{0.0, 0.0}));
+  auto shy = std::make_shared<ShyPlanner>();
+  sim.add_agents({Point{10.0, 10.0}, Point{11.0, 10.0}, Point{50.0, 50.0}}, std::make_shared<StubHighLevelPlan>(Vec2f{0.0, 1.0}),
+                 shy, 3.0);
+  sim.step(std::chrono::duration<double>(0.1));
+  CHECK(shy->calls == 3);
+  // agent 0 sees agent 1 at +1 m in x: w = (0, 1) - 0.5 * (1, 0); agent 1 the mirror image; agent 2 sees nobody
+  CHECK(std::hypot(sim.agents.at(0).position.x - (10.0 - 0.05), sim.agents.at(0).position.y - 10.1) < 1e-5);
+  CHECK(std::hypot(sim.agents.at(1).position.x - (11.0 + 0.05), sim.agents.at(1).position.y - 10.1) < 1e-5);
+  CHECK(std::hypot(sim.agents.at(2).position.x - 50.0, sim.agents.at(2).position.y - 50.1) < 1e-5);
+}
+
 int main() {
+  test_user_local_planner();
   test_snapshots();
   test_step_integration();
   test_event_listener_source_sink_api();
   test_index_out_of_bounds_is_an_error();
   test_viz_scene();
-  std::printf("5 passed\n");
+  std::printf("6 passed\n");
   return 0;
 }

@@ -31,4 +31,4 @@ def test_reference_step_tests_in_cpp():
     exe = build_cpp_test()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
-    assert out.returncode == 0 and "5 passed" in out.stdout
+    assert out.returncode == 0 and "6 passed" in out.stdout
