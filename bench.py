@@ -283,9 +283,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
         from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
-        # (longer lanes on more GPUs keep the number of sinks, one planner group each, under the engine's group limit)
-        lane_length = 16.0 * max(1, (world + 1) // 2) if scaling == "weak" else 16.0
-        lanes, grid, fill_steps = scenes.stream_lanes(n_total, lane_length=lane_length, cell_size=args.cell)
+        lanes, grid, fill_steps = scenes.stream_lanes(n_total, lane_length=16.0, cell_size=args.cell)
         extent = grid["width"]
         if world == 1:
             tiling = (1, 1)

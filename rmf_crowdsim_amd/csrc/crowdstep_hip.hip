@@ -37,7 +37,7 @@
 #include "crowdstep.h"
 
 #define CS_INVALID_CELL 0xFFFFFFFFu
-#define CS_MAX_GROUPS 65535u  // the group index travels in 16 bits of `meta`
+#define CS_MAX_GROUPS 1048575u  // the group index travels in 16 or 20 bits of `meta` (GridDev::grp_bits)
 #define CS_SPAWN_OCCUPANCY_RADIUS 0.4  // hard-coded in the reference, lib.rs:212-214
 // Device ids are below 2^31 (`usize` in the reference): the tiled kernel reads "the neighbour's id is larger"
 // (right_of_way_vel, zanlungo.rs:173-198 with priority = id) off the sign of a 32-bit difference.
@@ -145,6 +145,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
     e->gdev.fix_inv = (float)std::ldexp(1.0, -bits);
     e->gdev.cs_fix = (int32_t)std::llrint(grid->cell_size * std::ldexp(1.0, bits));
   }
+  e->gdev.grp_bits = 16u;  // (cs_engine::room_for_group widens it)
   if (cfg && cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
@@ -245,10 +246,7 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
     e->error = "unknown planner handle";
     return 2;
   }
-  if (e->groups.size() + 1 >= CS_MAX_GROUPS) {
-    e->error = "too many distinct (planner, eyesight) groups";
-    return 5;
-  }
+  if (int rc = e->room_for_group(0)) return rc;
   uint32_t g = e->make_group(hlp, lp, eyesight, -1);
   return e->add_agents(xy, n, g, UINT32_MAX, out_ids);
 }
@@ -279,7 +277,7 @@ int cs_remove_agent(cs_engine* e, uint64_t id) {
     e->error = "unknown agent id";
     return 2;
   }
-  const HostGroup& g = e->groups[found[1] & 0xFFFFu];
+  const HostGroup& g = e->groups[meta_group(e->gdev, found[1])];
   const cs_hlp_desc& p = e->hlps[g.hlp];
   if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, id);
   e->sorted = false;
@@ -313,10 +311,12 @@ uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
 }
 
 uint32_t cs_add_source_sink(cs_engine* e, const cs_source_sink_desc* d) {
-  if (e->groups.size() + 1 >= CS_MAX_GROUPS || d->n_waypoints == 0 || d->n_waypoints > 65535) {
-    e->error = "too many source-sinks / planner groups (65535) or bad waypoint count";
+  if (d->n_waypoints == 0) {
+    e->error = "a source-sink needs at least one waypoint";
     return UINT32_MAX;
   }
+  hipSetDevice(e->device);
+  if (e->room_for_group(d->n_waypoints)) return UINT32_MAX;
   HostSink s;
   s.d = *d;
   s.waypoints.assign(d->waypoints_xy, d->waypoints_xy + 2 * d->n_waypoints);
@@ -404,8 +404,8 @@ size_t cs_read_agents(cs_engine* e, cs_agent_view* out, size_t cap) {
     e->to_global(h.cell[i], h.off[i].x, h.off[i].y, &out[k].x, &out[k].y);
     out[k].vx = h.vel[i].x;
     out[k].vy = h.vel[i].y;
-    out[k].next_waypoint = h.meta[i] >> 16;
-    out[k].eyesight_range = e->groups[h.meta[i] & 0xFFFFu].eyesight;
+    out[k].next_waypoint = meta_waypoint(e->gdev, h.meta[i]);
+    out[k].eyesight_range = e->groups[meta_group(e->gdev, h.meta[i])].eyesight;
   }
   return n;
 }
@@ -604,7 +604,7 @@ static int lp_callbacks_eval(cs_engine* e, const StepParams& P, const EpilogueCt
   std::vector<std::vector<uint32_t>> by_lp(e->lp_kinds.size());
   for (uint32_t i = 0; i < n; ++i) {
     if (h.cell[i] == CS_INVALID_CELL) continue;
-    const auto& g = e->groups[h.meta[i] & 0xFFFFu];
+    const auto& g = e->groups[meta_group(e->gdev, h.meta[i])];
     if (e->lp_kinds[g.lp] != 2u) continue;
     if (e->tile) {
       const uint32_t cx = h.cell[i] / (uint32_t)e->nx, cy = h.cell[i] - cx * (uint32_t)e->nx;
@@ -629,8 +629,8 @@ static int lp_callbacks_eval(cs_engine* e, const StepParams& P, const EpilogueCt
     a.vy = h.vel[i].y;
     a.preferred_vx = pvx;
     a.preferred_vy = pvy;
-    a.eyesight_range = e->groups[h.meta[i] & 0xFFFFu].eyesight;
-    a.next_waypoint = h.meta[i] >> 16;
+    a.eyesight_range = e->groups[meta_group(e->gdev, h.meta[i])].eyesight;
+    a.next_waypoint = meta_waypoint(e->gdev, h.meta[i]);
     return a;
   };
   std::vector<float2> out(n, make_float2(0.f, 0.f));

@@ -161,6 +161,48 @@ def test_config3_one_million_agents_sustained_by_source_sinks():
     assert nearest.max() < 0.5
 
 
+def test_two_hundred_thousand_source_sinks_on_one_engine():
+    """Every source-sink is a planner group, and the group index travels in the agents' `meta` word: 16 bits of
+    it until an engine has more than 65,535 groups, 20 from then on (the live agents' words are re-packed in
+    place; round 2 refused the 65,536th sink and bench.py lengthened its lanes to stay below).  configs[3]'s
+    stream cut into 200,000 short lanes (2 m, five walkers each): the switch happens in the middle of
+    registration AFTER a first batch of sinks has already spawned agents, so words of both packings are
+    re-packed.  Tiled = gather = 1 x 1 mesh bit for bit; ids unique; alive = spawned - destroyed."""
+    lanes, grid, fill_steps = scenes.stream_lanes(1_000_000, lane_length=2.0, cell_size=2.0)
+    assert len(lanes) == 200_000
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    runs = {}
+    for name in ("tiled", "gather", "mesh"):
+        if name == "mesh":
+            t = LocalTileMesh(LocationHash2D(**grid), (1, 1), halo_cells=1, capacity_hint=1_200_000)
+        else:
+            t = Simulation(LocationHash2D(**grid), flags=2 if name == "tiled" else 1, capacity_hint=1_200_000)
+        _stream(t, lanes[:60_000], lp, 2.0)
+        for _ in range(12):  # agents of the first sinks exist (16-bit packing) when the 65,536th group arrives
+            t.step(0.05, report=False)
+        _stream(t, lanes[60_000:], lp, 2.0)
+        spawned = destroyed = 0
+        for k in range(fill_steps + 10):
+            t.step(0.05, report=name != "mesh")
+            if name != "mesh":
+                spawned += t.last_report["n_spawned"]
+                destroyed += t.last_report["n_destroyed"]
+        runs[name] = (t.read_agents(), spawned, destroyed)
+    a, spawned, destroyed = runs["tiled"]
+    print(f"200,000 sinks: {len(a)} agents alive, {spawned} spawned and {destroyed} destroyed after the second batch")
+    assert 500_000 < len(a) <= 1_050_000 and destroyed > 100_000
+    assert len(np.unique(a["id"])) == len(a)
+    assert (spawned, destroyed) == runs["gather"][1:]
+    assert a.tobytes() == runs["gather"][0].tobytes() == runs["mesh"][0].tobytes()
+    assert np.isfinite(a["x"]).all() and (a["next_waypoint"] == 0).all()
+    # a 1,048,576th group, or a source-sink with more waypoints than the narrower counter holds, is refused
+    small = Simulation(LocationHash2D(**grid))
+    _stream(small, lanes[:66_000], lp, 2.0)
+    with pytest.raises(Exception, match="4,095 waypoints"):
+        small.add_source_sink(SourceSink((10.0, 10.0), 0.5, MonotonicCrowd(1000.0), StubHighLevelPlan((0.0, 1.0)), lp,
+                                         [(10.0, 10.0 + 0.001 * k) for k in range(5000)], False, 2.0))
+
+
 def test_config4_four_million_agents_with_hotspots():
     """configs[4] at full size: 4M agents, half a uniform background, half in Gaussian hotspots
     (up to 4.9 agents/m^2: neighbour lists beyond 64 entries, windows walked in chunks).  Tiled
