@@ -331,11 +331,23 @@ struct Zanlungo : LocalPlanner {
     return kInf;
   }
 
+  // A diagnosis the reference does not make (test infrastructure: the parity tests name the agents they leave
+  // out).  time_to_collision returns 0, "colliding now", for a pair that is NOT inside the collision distance when
+  // |rel_vel|^2 underflows (f64: |rel_vel| ~ 1e-162) while b does not: root > |b| numerically, t0 = -inf, t1 = +inf.
+  // The agent then gets 0/0 = NaN from its neighbours without right of way.  Such a pair is
+  // told apart from a real overlap by c > 0.
+  bool spurious_collision(V2 rel_vel, V2 rel_pos, Real t) const {
+    return t == Real(0) && norm2(rel_pos) - agent_radius * agent_radius > Real(0) && norm2(rel_vel) < Real(1e-30);
+  }
+  mutable std::vector<uint64_t>* spurious_victims = nullptr;  // ids whose t_i came out 0 through such a pair
+
   // :76-91 — strict `<` from +inf, all neighbours regardless of id
   Real compute_tti(const Agent& me, const std::vector<Agent>& nearby) const {
     Real t_i = kInf;
     for (const Agent& n : nearby) {
       Real t = time_to_collision(n.velocity - me.velocity, n.position - me.position);
+      if (spurious_victims && spurious_collision(n.velocity - me.velocity, n.position - me.position, t))
+        spurious_victims->push_back(me.agent_id);
       if (t < t_i) t_i = t;
     }
     return t_i;
@@ -616,6 +628,7 @@ struct cs_engine {
   // whether j's index entry is still the old position or already the new one, i.e. where the
   // reference's in-loop index update (lib.rs:299) could make it differ from the Jacobi result
   bool count_shell = false;
+  std::vector<uint64_t> spurious_victims;  // (oracle_spurious_victims)
   uint64_t last_shell_crossings = 0;
 
   explicit cs_engine(const cs_grid_desc& g)
@@ -1188,6 +1201,14 @@ void oracle_index_remove(cs_engine* e, uint64_t id) { e->index.remove_agent(id);
 // certification of a parity scene (row a2): count, for the steps that follow, the neighbour pairs
 // that sit on the eyesight shell during the step; read the last step's count back
 void oracle_count_shell_crossings(cs_engine* e, int on) { e->count_shell = on != 0; }
+// ids of the agents whose t_i came out 0 through an underflowed pair so far (Zanlungo::spurious_collision), with
+// repeats; recorded from the call on.  Returns the number of records (may exceed cap).
+size_t oracle_spurious_victims(cs_engine* e, uint64_t* out, size_t cap) {
+  for (auto& lp : e->lps)
+    if (auto* z = dynamic_cast<Zanlungo*>(lp.get())) z->spurious_victims = &e->spurious_victims;
+  for (size_t k = 0; k < e->spurious_victims.size() && k < cap; ++k) out[k] = e->spurious_victims[k];
+  return e->spurious_victims.size();
+}
 uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; }
 
 // ---------------------------------------------------------------------------
@@ -1201,7 +1222,9 @@ uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; 
 double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
                          double force_distance, double agent_mass, double agent_radius, double eyesight,
                          double width, double height, double cell_size, double off_x, double off_y,
-                         double dt_seconds, uint32_t steps, int threads) {
+                         double dt_seconds, uint32_t steps, int threads, uint8_t* spurious_out) {
+  // spurious_out (may be null): set to 1 for every agent whose t_i came out 0 through an underflowed pair in some
+  // step (Zanlungo::spurious_collision)
   Zanlungo lp;
   lp.agent_scale = (Real)agent_scale;
   lp.obstacle_scale = Real(1);
@@ -1275,6 +1298,8 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
         Real t_i = kInf;
         for (const Agent* o : nearby) {
           const Real t = lp.time_to_collision(o->velocity - me.velocity, o->position - me.position);
+          if (spurious_out && lp.spurious_collision(o->velocity - me.velocity, o->position - me.position, t))
+            spurious_out[i] = 1;  // (this agent's own byte: no race)
           if (t < t_i) t_i = t;
         }
         V2 force = {Real(0), Real(0)};

@@ -38,7 +38,10 @@ def load_oracle(kind="f64"):
     lib.oracle_shell_crossings.argtypes = [ctypes.c_void_p]
     lib.oracle_fast_steps.restype = ctypes.c_double
     lib.oracle_fast_steps.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
-                                      [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int])
+                                      [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int,
+                                                                 ctypes.POINTER(ctypes.c_uint8)])
+    lib.oracle_spurious_victims.restype = ctypes.c_size_t
+    lib.oracle_spurious_victims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
     dp = ctypes.POINTER(ctypes.c_double)
     lib.oracle_zanlungo_pair_force.restype = None
     lib.oracle_zanlungo_pair_force.argtypes = [dp, dp, dp, ctypes.c_double, dp]
@@ -56,6 +59,15 @@ class OracleSimulation(Simulation):
     def _load_library(self):
         return load_oracle(self._kind)
 
+    def spurious_victims(self):
+        """Ids (a set) of the agents whose t_i came out 0 through a pair whose |rel_vel|^2 underflowed: the
+        reference's f64 flaw of DESIGN.md section 5.  Recorded from the first call on: call it once before stepping."""
+        import numpy as np
+        n = self._lib.oracle_spurious_victims(self._engine, None, 0)
+        buf = np.zeros(max(n, 1), dtype=np.uint64)
+        self._lib.oracle_spurious_victims(self._engine, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n)
+        return set(int(i) for i in buf[:n])
+
     def count_shell_crossings(self, on=True):
         """from now on count, per step, the ordered neighbour pairs whose
         membership would depend on the reference's visiting order."""
@@ -70,9 +82,10 @@ class OracleSimulationF32(OracleSimulation):
     _kind = "f32"
 
 
-def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=None):
+def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=None, spurious=None):
     """The OpenMP / cell-sorted CPU baseline (oracle_fast_steps): same arithmetic as the oracle,
-    not the reference's data structures.  Returns (positions, velocities, seconds)."""
+    not the reference's data structures.  Returns (positions, velocities, seconds).  `spurious`: a uint8 array
+    of len(pts) that gets a 1 for every agent whose t_i came out 0 through an underflowed pair in some step."""
     import numpy as np
     lib = load_oracle("f64")
     xy = np.ascontiguousarray(pts, dtype=np.float64).copy()
@@ -82,5 +95,6 @@ def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=No
     A, _, _, D, m, R = zanlungo
     sec = lib.oracle_fast_steps(len(xy), xy.ctypes.data_as(dp), v.ctypes.data_as(dp), pv.ctypes.data_as(dp),
                                 A, D, m, R, eyesight, grid["width"], grid["height"], grid["cell_size"],
-                                grid["offset"][0], grid["offset"][1], dt, steps, threads)
+                                grid["offset"][0], grid["offset"][1], dt, steps, threads,
+                                None if spurious is None else spurious.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
     return xy, v, sec

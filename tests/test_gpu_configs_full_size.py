@@ -43,6 +43,7 @@ def test_config1_exact_size():
     for name, cls in (("gpu", Simulation), ("o32", OracleSimulationF32), ("o64", OracleSimulation)):
         sims[name] = cls(LocationHash2D(**grid))
         scenes.add_counterflow(sims[name], pts, group, scenes.CREEP_SPEED, lp, 2.0)
+    sims["o64"].spurious_victims()  # (starts the oracle's record of the agents its f64 flaw strikes)
     worst = 0.0
     for k in range(8):
         for s in sims.values():
@@ -50,7 +51,8 @@ def test_config1_exact_size():
         a, b = sims["gpu"].read_agents(), sims["o64"].read_agents()
         assert len(a) == n and np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
         ok = np.isfinite(b["x"])
-        assert (~ok).sum() <= n // 2000
+        # left out: exactly the agents the oracle names as victims of the flaw, nobody else (5 when this was written)
+        assert set(int(i) for i in b["id"][~ok]) == sims["o64"].spurious_victims() and (~ok).sum() <= 10
         worst = max(worst, _rel(a, b, extent, ok))
         assert sims["gpu"].last_report["n_tti_zero"] == 0 and sims["gpu"].last_report["n_nonfinite"] == 0
     c = sims["o32"].read_agents()
@@ -92,11 +94,14 @@ def test_config1_full_size_for_the_north_star_s_1000_steps():
     by_id[ids] = pts
     pref = np.zeros_like(pts)
     pref[ids, 1] = np.where(group == 0, scenes.CREEP_SPEED, -scenes.CREEP_SPEED)
+    struck = np.zeros(n, dtype=np.uint8)
     xy, vel, sec = fast_steps(by_id, pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, steps,
-                              threads=min(16, os.cpu_count() or 1))
+                              threads=min(16, os.cpu_count() or 1), spurious=struck)
     assert sec > 0
     ok = np.isfinite(xy).all(axis=1)
-    assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all() and (~ok).sum() <= n // 200
+    # left out: exactly the agents struck by the flaw (the CPU side reports them), nobody else (30 when this was written)
+    assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
+    assert ((~ok) == (struck != 0)).all() and (~ok).sum() <= 60
     dp = np.hypot(a["x"] - xy[:, 0], a["y"] - xy[:, 1])[ok]
     force = np.hypot(vel[ok, 0], np.abs(vel[ok, 1]) - scenes.CREEP_SPEED)
     print(f"configs[1], 1000 steps: |dp|/L = {dp.max() / extent:.2e} (p99.9 {np.quantile(dp, 0.999) / extent:.2e}); "

@@ -228,6 +228,40 @@ def test_config1_256_agents_1000_steps():
     assert worst <= 1e-4 and dv <= 1e-4
 
 
+def test_config1_at_the_visualisers_speed_until_the_model_dies():
+    """configs[0] at the visualiser's own speed, 10 units/s (rmf_crowdsim_viz/src/main.rs:26-29), where the
+    reference's model is violent: within five steps somebody is thrown at 2,000 units/s, at step 6 the first
+    agents are NaN (t_i = 0: 0/0 for the neighbours without right of way, KAT-Z3), and step 54 returns
+    Err("Index out of bounds") when a thrown agent leaves the grid.  The engine lives and dies the same way: the
+    same agents go NaN at the same steps, the others stay within 2e-4 of L of the oracle's for the first 30 steps and
+    within 1e-3 until the end (1.2e-4 / 4.3e-4 when this was written: the agents in flight), and the same step fails with the same error string."""
+    sim, ora = _viz(Simulation, speed=10.0), _viz(OracleSimulation, speed=10.0)
+    died = {}
+    worst, worst_calm, lost, compared = 0.0, 0.0, 0, 0
+    for k in range(120):
+        for name, s in (("engine", sim), ("oracle", ora)):
+            try:
+                s.step(0.05)
+            except Exception as err:  # CrowdSimError
+                died[name] = (k, str(err))
+        if died:
+            break
+        a, b = sim.read_agents(), ora.read_agents()
+        gone_a, gone_b = ~np.isfinite(a["x"]), ~np.isfinite(b["x"])
+        assert (a["id"] == b["id"]).all() and (gone_a == gone_b).all(), f"step {k}: NaN agents differ"
+        ok = ~gone_b
+        dp = np.hypot(a["x"] - b["x"], a["y"] - b["y"]) / 1000.0
+        worst = max(worst, float(dp[ok].max()))
+        if k < 30:
+            worst_calm = worst
+        lost, compared = int(gone_b.sum()), k + 1
+    print(f"configs[0] at speed 10: {compared} steps compared, worst |dp|/L {worst:.2e} ({worst_calm:.2e} over the first 30 "
+          f"steps), {lost} agents NaN at the end; died: {died}")
+    assert died == {"engine": (54, "Index out of bounds"), "oracle": (54, "Index out of bounds")}
+    # (an agent in flight at 3e4 units/s covers 1.5 L per step: 4e-4 of L on it is 3e-4 of its own step)
+    assert compared == 54 and lost >= 2 and worst_calm <= 2e-4 and worst <= 1e-3
+
+
 # ---- steps at scale: every branch of the kernel against the oracle ----------------------
 def _crowd(cls, n, cell, eyesight, speed, flags=0, seed=11):
     pts, grid, extent, group = scenes.uniform_crowd(n, seed=seed, cell_size=cell)
@@ -301,6 +335,7 @@ def test_creeping_counterflow_1000_steps():
     n = 10000
     sim, extent = _crowd(Simulation, n, 2.0, 2.0, scenes.CREEP_SPEED, seed=23)
     ora, _ = _crowd(OracleSimulation, n, 2.0, 2.0, scenes.CREEP_SPEED, seed=23)
+    ora.spurious_victims()  # (starts the record)
     for k in range(999):
         sim.step(0.05, report=False)
         ora.step(0.05)
@@ -314,7 +349,9 @@ def test_creeping_counterflow_1000_steps():
     # exactly 0), so those agents are excluded; the engine itself must stay finite.
     assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
     ok = np.isfinite(b["x"])
-    assert (~ok).sum() <= n // 200
+    # ... and they are exactly the agents the oracle itself names as victims of that flaw (11 of them when this
+    # was written): nobody is left out for any other reason
+    assert set(int(i) for i in b["id"][~ok]) == ora.spurious_victims() and (~ok).sum() <= 22
     dp = np.hypot(a["x"] - b["x"], a["y"] - b["y"])[ok]
     err = float(dp.max() / extent)
     dv = np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"])[ok]
@@ -322,6 +359,80 @@ def test_creeping_counterflow_1000_steps():
     print(f"1000 steps: |dp|/L = {err:.2e}; |dv| p99.9 / max|F| = "
           f"{float(np.quantile(dv, 0.999) / force.max()):.2e}; reference-path NaN agents: {int((~ok).sum())}")
     assert err <= 1e-4
+
+
+def crossing_flows(n, density=0.3, angle_deg=30.0, speed=scenes.WALK_SPEED, seed=5):
+    """Two interleaved groups on a jittered lattice of `density` agents / m^2, one walking along +x, the other at
+    `angle_deg` to it, both at walking speed: points, preferred velocity per point, group per point, grid."""
+    spacing = 1.0 / np.sqrt(density)
+    side = int(np.ceil(np.sqrt(n)))
+    pts = scenes.jittered_lattice(n, spacing, (40.0, 40.0), 0.25, seed)
+    k = np.arange(n)
+    group = ((k % side) + (k // side)) % 2
+    th = np.radians(angle_deg)
+    pref = np.where(group[:, None] == 0, np.array([speed, 0.0]), np.array([speed * np.cos(th), speed * np.sin(th)]))
+    size = float(np.ceil(side * spacing + 120.0))
+    return pts, pref, group, dict(width=size, height=size, cell_size=2.0, offset=(0.0, 0.0)), side * spacing
+
+
+CROSSING_ZANLUNGO = (0.3, 1.0, 0.0, 0.4, 2.0, 0.2)
+
+
+def test_crossing_flows_at_walking_speed_300_steps():
+    """Forces of WALKING magnitude over a long run (the review of round 2: every long parity scene was the 1 mm/s
+    creep, or the walking crowd whose force underflows to exactly 0).  A head-on counter-flow at walking speed
+    does not survive on the reference's own f64 path; two sparse flows (0.3 agents / m^2) crossing
+    at 30 degrees at 1.3 m/s do: the oracle runs 300 steps without a NaN, a spurious collision or an agent
+    leaving the grid, while at any moment a few per cent of the agents are dodging with forces of 0.1-3 m/s
+    (t_i of a second or two), in bursts of up to a tenth of the crowd as the two lattices pass through each other.
+    Engine vs oracle every 50 steps."""
+    from oracle_sim import fast_steps
+    n, steps = 4000, 300
+    pts, pref, group, grid, extent = crossing_flows(n)
+    lp = Zanlungo(*CROSSING_ZANLUNGO)
+    th = np.radians(30.0)
+    runs = {}
+    for flags in (2, 1):  # tiled, gather
+        sim = Simulation(LocationHash2D(**grid), flags=flags)
+        ids0 = sim.add_agents(pts[group == 0], StubHighLevelPlan((scenes.WALK_SPEED, 0.0)), lp, 2.0)
+        ids1 = sim.add_agents(pts[group == 1], StubHighLevelPlan((scenes.WALK_SPEED * np.cos(th), scenes.WALK_SPEED * np.sin(th))), lp, 2.0)
+        runs[flags] = sim
+    by_id = np.concatenate([pts[group == 0], pts[group == 1]])
+    pref_by_id = np.concatenate([pref[group == 0], pref[group == 1]])
+    assert ids0[0] == 0 and ids1[-1] == n - 1
+    xy, vel = by_id.copy(), None
+    struck = np.zeros(n, dtype=np.uint8)
+    worst = worst_dv = worst_tail = dodging = 0.0
+    beyond = 0
+    strongest = []
+    for chunk in range(steps // 50):
+        xy, vel, sec = fast_steps(xy, pref_by_id, CROSSING_ZANLUNGO, 2.0, grid, 0.05, 50, threads=8, vel=vel, spurious=struck)
+        assert sec >= 0 and np.isfinite(xy).all() and np.isfinite(vel).all() and not struck.any()  # the scene is certified
+        for sim in runs.values():
+            for _ in range(49):
+                sim.step(0.05, report=False)
+            sim.step(0.05)
+            assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0
+        a, g = runs[2].read_agents(), runs[1].read_agents()
+        assert a.tobytes() == g.tobytes()
+        force = np.hypot(vel[:, 0] - pref_by_id[:, 0], vel[:, 1] - pref_by_id[:, 1])   # |F| / m, m/s
+        strongest.append(float(force.max()))
+        dps = np.hypot(a["x"] - xy[:, 0], a["y"] - xy[:, 1]) / extent
+        dp = float(dps.max())
+        dv = float(np.hypot(a["vx"] - vel[:, 0], a["vy"] - vel[:, 1]).max() / max(force.max(), 1e-9))
+        worst, worst_dv = max(worst, dp), max(worst_dv, dv)
+        worst_tail = max(worst_tail, float(np.quantile(dps, 0.999)))
+        dodging = max(dodging, float(np.mean(force > 0.01 * scenes.WALK_SPEED)))
+        beyond = max(beyond, int((dps > 1e-5).sum()))
+        print(f"crossing flows, step {50 * (chunk + 1)}: |dp|/L max {dp:.2e} p99.9 {float(np.quantile(dps, 0.999)):.2e} "
+              f"(agents beyond 1e-5: {int((dps > 1e-5).sum())}), max|dv|/max|F| {dv:.2e}, max|F|/m {force.max():.2f} m/s, "
+              f"dodging now {float(np.mean(force > 0.013)):.3f}")
+    assert max(strongest) > 1.0 and np.median(strongest) > 0.3 and dodging > 0.05   # forces of walking magnitude were at work
+    # A dodge is a discontinuity of the model (a neighbour enters the eyesight, a grazing pair's discriminant changes
+    # sign): an agent whose f32 and f64 copies take such a decision one step apart ends up centimetres away (one of
+    # these 4,000 does: 1.0e-4 of L).  p99.9 stays within 1e-5 of L, at most three agents go beyond that, nobody beyond 1e-3.
+    assert worst_tail <= 1e-5 and worst <= 1e-3 and beyond <= 3
+    assert worst_dv <= 2e-3
 
 
 def test_walking_crowd_300_steps():
