@@ -167,9 +167,14 @@ struct LocalPlanner {
         },
         this);
   }
+  // (a tile mesh evaluates planners on every tile: the device planners register as data, host code does not)
+  virtual uint32_t register_with(cs_mesh*) {
+    throw std::runtime_error("a host LocalPlanner runs on a single engine (Simulation), not on a tile mesh");
+  }
 };
 struct NoLocalPlan : LocalPlanner {  // no_local_plan.rs:7-18
   uint32_t register_with(cs_engine* e) override { return cs_register_no_local_plan(e); }
+  uint32_t register_with(cs_mesh* m) override { return cs_mesh_register_no_local_plan(m); }
 };
 struct Zanlungo : LocalPlanner {  // zanlungo.rs:31-48
   cs_zanlungo_params p;
@@ -177,6 +182,7 @@ struct Zanlungo : LocalPlanner {  // zanlungo.rs:31-48
            double agent_mass, double agent_radius)
       : p{agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass, agent_radius} {}
   uint32_t register_with(cs_engine* e) override { return cs_register_zanlungo(e, &p); }
+  uint32_t register_with(cs_mesh* m) override { return cs_mesh_register_zanlungo(m, &p); }
 };
 
 struct CrowdGenerator {  // source_sink.rs:30-33
@@ -352,6 +358,142 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
   std::map<const void*, uint32_t> handles_;
   std::vector<std::shared_ptr<void>> keep_;
   std::vector<std::shared_ptr<SourceSink>> sinks_;
+  std::map<std::size_t, std::shared_ptr<EventListener>> listeners_;
+  std::size_t next_listener_ = 0;
+};
+
+// The same `Simulation`, cut into tiles_x x tiles_y spatial tiles: one tile engine per tile behind
+// the C ABI's mesh handle (cs_mesh_*: layout, halo exchange, spawn flags, route misses, re-cuts, merged queries all
+// in the library).  With `rccl_unique_id` (CS_RCCL_UNIQUE_ID_BYTES from cs_rccl_unique_id on one rank) the
+// distributed form: one tile per rank and GPU, `agents` then holds this rank's share.  Results equal Simulation's
+// bit for bit while nobody touches the domain's edges.
+class TiledSimulation {
+ public:
+  std::unordered_map<AgentId, Agent> agents;  // lib.rs:71, refreshed after every mutating call
+
+  TiledSimulation(const LocationHash2D& index, uint32_t tiles_x, uint32_t tiles_y, uint32_t halo_cells, int device = 0,
+                  const uint8_t* rccl_unique_id = nullptr, int rank = 0, int n_ranks = 1, double density_per_cell = 16.0) {
+    cs_grid_desc g{index.width, index.height, index.cell_size, index.offset.x, index.offset.y};
+    cs_mesh_desc d{};
+    d.tiles_x = tiles_x;
+    d.tiles_y = tiles_y;
+    d.halo_cells = halo_cells;
+    d.device_ordinal = device;
+    d.rank = rank;
+    d.n_ranks = n_ranks;
+    d.density_per_cell = density_per_cell;
+    d.rccl_unique_id = rccl_unique_id;
+    mesh_ = cs_mesh_create(&g, &d);
+    if (!mesh_) throw std::runtime_error(std::string("cs_mesh_create failed: ") + cs_mesh_last_error(nullptr));
+  }
+  ~TiledSimulation() { cs_mesh_destroy(mesh_); }
+  TiledSimulation(const TiledSimulation&) = delete;
+  TiledSimulation& operator=(const TiledSimulation&) = delete;
+
+  std::vector<AgentId> add_agents(const std::vector<Point>& spawn_positions, std::shared_ptr<HighLevelPlanner> hlp,
+                                  std::shared_ptr<LocalPlanner> lp, double agent_eyesight_range) {  // lib.rs:119-156
+    std::vector<double> xy;
+    for (const Point& p : spawn_positions) {
+      xy.push_back(p.x);
+      xy.push_back(p.y);
+    }
+    std::vector<uint64_t> ids(spawn_positions.size());
+    const int rc = cs_mesh_add_agents(mesh_, xy.data(), ids.size(), handle(hlp), handle(lp), agent_eyesight_range, ids.data());
+    refresh();
+    if (rc != 0) throw std::runtime_error(cs_mesh_last_error(mesh_));
+    return std::vector<AgentId>(ids.begin(), ids.end());
+  }
+  std::size_t add_source_sink(std::shared_ptr<SourceSink> s) {  // lib.rs:159-161
+    cs_source_sink_desc d{};
+    d.source_x = s->source.x;
+    d.source_y = s->source.y;
+    d.radius_sink = s->radius_sink;
+    s->crowd_generator->fill(&d);
+    d.hlp = handle(s->high_level_planner);
+    d.lp = handle(s->local_planner);
+    std::vector<double> wps;
+    for (const Vec2f& w : s->waypoints) {
+      wps.push_back(w.x);
+      wps.push_back(w.y);
+    }
+    d.waypoints_xy = wps.data();
+    d.n_waypoints = s->waypoints.size();
+    d.loop_forever = s->loop_forever ? 1 : 0;
+    d.agent_eyesight_range = s->agent_eyesight_range;
+    keep_.push_back(s);
+    const uint32_t sink = cs_mesh_add_source_sink(mesh_, &d);
+    if (sink == UINT32_MAX) throw std::runtime_error(cs_mesh_last_error(mesh_));
+    return sink;
+  }
+  void remove_source_sink(std::size_t id) { cs_mesh_remove_source_sink(mesh_, (uint32_t)id); }  // lib.rs:164
+  std::size_t add_event_listener(std::shared_ptr<EventListener> l) {                           // lib.rs:171
+    listeners_[next_listener_] = std::move(l);
+    cs_mesh_event_recording(mesh_, 1);
+    return next_listener_++;
+  }
+  void remove_agents(AgentId agent) {  // lib.rs:176-192
+    const int rc = cs_mesh_remove_agent(mesh_, agent);
+    refresh();
+    if (rc != 0) throw std::runtime_error(cs_mesh_last_error(mesh_));
+  }
+  void step(std::chrono::duration<double> dur) {  // lib.rs:195-383
+    cs_step_report rep;
+    const int rc = cs_mesh_step(mesh_, dur.count(), &rep);
+    refresh();
+    if (rc != 0) throw std::runtime_error(cs_mesh_last_error(mesh_));
+  }
+  void step_no_readback(std::chrono::duration<double> dur) {  // nothing waits for the device
+    if (cs_mesh_step(mesh_, dur.count(), nullptr) != 0) throw std::runtime_error(cs_mesh_last_error(mesh_));
+  }
+  void recut() {  // cuts to the quantiles of where the crowd stands now (in-process form)
+    if (cs_mesh_recut(mesh_) != 0) throw std::runtime_error(cs_mesh_last_error(mesh_));
+  }
+  cs_mesh* handle() { return mesh_; }
+
+ private:
+  template <class P>
+  uint32_t handle(const std::shared_ptr<P>& p) {
+    auto it = handles_.find(p.get());
+    if (it != handles_.end()) return it->second;
+    const uint32_t h = register_planner(p.get());
+    if (h == UINT32_MAX) throw std::runtime_error(cs_mesh_last_error(mesh_));
+    handles_[p.get()] = h;
+    keep_.push_back(p);
+    return h;
+  }
+  uint32_t register_planner(HighLevelPlanner* p) {
+    cs_hlp_desc d = p->describe();
+    return cs_mesh_register_hlp(mesh_, &d);
+  }
+  uint32_t register_planner(LocalPlanner* p) { return p->register_with(mesh_); }
+  void refresh() {
+    cs_event ev[256];
+    for (;;) {
+      const std::size_t n = cs_mesh_drain_events(mesh_, ev, 256);
+      for (std::size_t i = 0; i < n; ++i)
+        for (auto& kv : listeners_) {
+          if (ev[i].kind == CS_EVENT_SPAWNED) kv.second->agent_spawned({ev[i].x, ev[i].y}, ev[i].id);
+          if (ev[i].kind == CS_EVENT_DESTROYED) kv.second->agent_destroyed(ev[i].id);
+        }
+      if (n < 256) break;
+    }
+    std::vector<cs_agent_view> v(cs_mesh_agent_count(mesh_));
+    const std::size_t got = cs_mesh_read_agents(mesh_, v.data(), v.size());
+    agents.clear();
+    for (std::size_t i = 0; i < got && got != SIZE_MAX; ++i) {
+      Agent a;
+      a.agent_id = v[i].id;
+      a.position = {v[i].x, v[i].y};
+      a.velocity = {v[i].vx, v[i].vy};
+      a.next_waypoint = v[i].next_waypoint;
+      a.eyesight_range = v[i].eyesight_range;
+      agents[a.agent_id] = a;
+    }
+  }
+
+  cs_mesh* mesh_ = nullptr;
+  std::map<const void*, uint32_t> handles_;
+  std::vector<std::shared_ptr<void>> keep_;
   std::map<std::size_t, std::shared_ptr<EventListener>> listeners_;
   std::size_t next_listener_ = 0;
 };

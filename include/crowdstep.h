@@ -481,6 +481,56 @@ int cs_allreduce_max_i32_rccl(cs_engine*, int* values_dev, size_t n);
  * without listeners, host planners or multi-leg route sinks (they use the split calls). */
 int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
 
+/* ---- a crowd cut into spatial tiles behind one handle ------------------------------
+ * The multi-tile form of `Simulation` (lib.rs:69-192): layout (tensor-product cuts, even or at the quantiles of a
+ * set of positions), one tile engine per tile, halo buffers sized per direction, the exchange, the spawn flags OR-ed
+ * over the tiles, route-cache misses, re-cuts and merged spatial queries.  Results equal the single engine's bit
+ * for bit on scenes that stay clear of the domain's edges (a tile's grid edges are strict).
+ *   rccl_unique_id null   every tile in this process on ONE device (exchanges are device copies on a shared stream)
+ *   rccl_unique_id given  one tile per rank (n_ranks = tiles_x * tiles_y, also 1 x 1 with one rank), rank = tile index = tx * tiles_y + ty, halo records over RCCL from the
+ *                  engine itself; cs_mesh_step and cs_mesh_remove_agent are then collective; re-cuts and
+ *                  spatial queries across ranks stay with the host (cs_tile_* / cs_query_*_batch per tile)
+ * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics). */
+typedef struct cs_mesh cs_mesh;
+typedef struct cs_mesh_desc {
+  uint32_t tiles_x, tiles_y;   /* 4 x 2 on 8 GPUs (BASELINE.json configs[2]); x = the index location_to_index
+                                * multiplies by the row stride (location_hash_2d.rs:59) */
+  uint32_t halo_cells;         /* >= ceil(largest eyesight / cell size) */
+  uint32_t flags;              /* CS_CFG_* for every tile engine */
+  int32_t device_ordinal;      /* the HIP device of this process's tile(s) */
+  int32_t rank, n_ranks;       /* of the distributed form (rccl_unique_id given) */
+  double density_per_cell;     /* expected agents per cell: sizes the halo buffers (0 = 16) */
+  uint64_t capacity_hint;      /* per tile */
+  const double* weights_xy;    /* optional: n_weights positions; the cuts go to the quantiles of their */
+  size_t n_weights;            /*   row / column histograms (a clustered crowd, configs[4]) */
+  const uint8_t* rccl_unique_id; /* distributed form: CS_RCCL_UNIQUE_ID_BYTES from cs_rccl_unique_id on one rank */
+} cs_mesh_desc;
+cs_mesh* cs_mesh_create(const cs_grid_desc* grid, const cs_mesh_desc* desc);
+void cs_mesh_destroy(cs_mesh*);
+const char* cs_mesh_last_error(const cs_mesh*); /* null mesh: why the calling thread's last cs_mesh_create failed */
+size_t cs_mesh_local_tiles(const cs_mesh*);
+cs_engine* cs_mesh_tile(cs_mesh*, size_t local_index);
+int cs_mesh_tile_rect(const cs_mesh*, size_t local_index, uint32_t* rect4 /* cx0, cx1, cy0, cy1 */);
+uint32_t cs_mesh_register_zanlungo(cs_mesh*, const cs_zanlungo_params*);
+uint32_t cs_mesh_register_no_local_plan(cs_mesh*);
+uint32_t cs_mesh_register_hlp(cs_mesh*, const cs_hlp_desc*);
+int cs_mesh_add_agents(cs_mesh*, const double* xy, size_t n, uint32_t hlp, uint32_t lp, double eyesight,
+                       uint64_t* out_ids);                                        /* lib.rs:119-156 */
+uint32_t cs_mesh_add_source_sink(cs_mesh*, const cs_source_sink_desc*);           /* lib.rs:159 */
+void cs_mesh_remove_source_sink(cs_mesh*, uint32_t handle);                       /* lib.rs:164 */
+int cs_mesh_remove_agent(cs_mesh*, uint64_t id);                                  /* lib.rs:176-192 */
+void cs_mesh_event_recording(cs_mesh*, int on);
+size_t cs_mesh_drain_events(cs_mesh*, cs_event* out, size_t cap);
+int cs_mesh_step(cs_mesh*, double dt_seconds, cs_step_report* report);            /* lib.rs:195-383 */
+int cs_mesh_synchronize(cs_mesh*);
+size_t cs_mesh_agent_count(cs_mesh*);
+size_t cs_mesh_read_agents(cs_mesh*, cs_agent_view* out, size_t cap);             /* ascending id; SIZE_MAX on error */
+int cs_mesh_tile_counts(cs_mesh*, uint64_t* out_per_local_tile);
+int cs_mesh_recut(cs_mesh*);
+int cs_mesh_query_radius_batch(cs_mesh*, size_t n, const double* xy, const double* radius, size_t cap_per_query,
+                               uint64_t* out_ids, uint64_t* out_counts);          /* spatial_index.rs:4-14 */
+int cs_mesh_query_knn_batch(cs_mesh*, size_t n, const double* xy, size_t k, uint64_t* out_ids, uint64_t* out_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1137,6 +1137,68 @@ int cs_tile_step_rccl(cs_engine* e, double, cs_step_report*) {
   return 3;
 }
 
+// ---- cs_mesh_*: the reference is ONE process, so the oracle's "mesh" is one reference
+// simulation whatever the tiling asked for: the checker of a tile mesh is the untiled crowd.
+struct cs_mesh {
+  cs_engine* e = nullptr;
+  std::string error;
+};
+static thread_local std::string g_mesh_error;
+cs_mesh* cs_mesh_create(const cs_grid_desc* grid, const cs_mesh_desc* d) {
+  if (!grid || !d || d->tiles_x == 0 || d->tiles_y == 0 || d->halo_cells == 0) {
+    g_mesh_error = "cs_mesh_create: a grid, tiles_x, tiles_y >= 1 and halo_cells >= 1 are required";
+    return nullptr;
+  }
+  cs_engine* e = cs_create(grid, nullptr);
+  if (!e) {
+    g_mesh_error = cs_last_error(nullptr);
+    return nullptr;
+  }
+  cs_mesh* m = new cs_mesh();
+  m->e = e;
+  return m;
+}
+void cs_mesh_destroy(cs_mesh* m) {
+  if (!m) return;
+  cs_destroy(m->e);
+  delete m;
+}
+const char* cs_mesh_last_error(const cs_mesh* m) { return m ? cs_last_error(m->e) : g_mesh_error.c_str(); }
+size_t cs_mesh_local_tiles(const cs_mesh*) { return 1; }
+cs_engine* cs_mesh_tile(cs_mesh* m, size_t k) { return k == 0 ? m->e : nullptr; }
+int cs_mesh_tile_rect(const cs_mesh* m, size_t k, uint32_t* r) {
+  if (k) return 3;
+  r[0] = 0; r[1] = (uint32_t)sat_usize(m->e->index.height / m->e->index.resolution); r[2] = 0; r[3] = (uint32_t)m->e->index.stride();
+  return 0;
+}
+uint32_t cs_mesh_register_zanlungo(cs_mesh* m, const cs_zanlungo_params* p) { return cs_register_zanlungo(m->e, p); }
+uint32_t cs_mesh_register_no_local_plan(cs_mesh* m) { return cs_register_no_local_plan(m->e); }
+uint32_t cs_mesh_register_hlp(cs_mesh* m, const cs_hlp_desc* d) { return cs_register_hlp(m->e, d); }
+int cs_mesh_add_agents(cs_mesh* m, const double* xy, size_t n, uint32_t hlp, uint32_t lp, double eyesight, uint64_t* out) {
+  return cs_add_agents(m->e, xy, n, hlp, lp, eyesight, out);
+}
+uint32_t cs_mesh_add_source_sink(cs_mesh* m, const cs_source_sink_desc* d) { return cs_add_source_sink(m->e, d); }
+void cs_mesh_remove_source_sink(cs_mesh* m, uint32_t h) { cs_remove_source_sink(m->e, h); }
+int cs_mesh_remove_agent(cs_mesh* m, uint64_t id) { return cs_remove_agent(m->e, id); }
+void cs_mesh_event_recording(cs_mesh* m, int on) { cs_event_recording(m->e, on); }
+size_t cs_mesh_drain_events(cs_mesh* m, cs_event* out, size_t cap) { return cs_drain_events(m->e, out, cap); }
+int cs_mesh_step(cs_mesh* m, double dt, cs_step_report* r) { return cs_step(m->e, dt, r); }
+int cs_mesh_synchronize(cs_mesh* m) { return cs_synchronize(m->e); }
+size_t cs_mesh_agent_count(cs_mesh* m) { return cs_agent_count(m->e); }
+size_t cs_mesh_read_agents(cs_mesh* m, cs_agent_view* out, size_t cap) { return cs_read_agents(m->e, out, cap); }
+int cs_mesh_tile_counts(cs_mesh* m, uint64_t* out) {
+  out[0] = cs_agent_count(m->e);
+  return 0;
+}
+int cs_mesh_recut(cs_mesh*) { return 0; }  // (nothing to cut)
+int cs_mesh_query_radius_batch(cs_mesh* m, size_t n, const double* xy, const double* radius, size_t cap, uint64_t* out_ids,
+                               uint64_t* out_counts) {
+  return cs_query_radius_batch(m->e, n, xy, radius, cap, out_ids, out_counts, nullptr, nullptr);
+}
+int cs_mesh_query_knn_batch(cs_mesh* m, size_t n, const double* xy, size_t k, uint64_t* out_ids, uint64_t* out_counts) {
+  return cs_query_knn_batch(m->e, n, xy, k, out_ids, out_counts, nullptr);
+}
+
 // Oracle-only probes used by tests/test_oracle_reference_kats.py to pin the
 // private pieces the reference's own unit tests reach (zanlungo.rs:225-236).
 double oracle_time_to_collision(double agent_radius, double rvx, double rvy, double rpx,

@@ -98,6 +98,14 @@ class SourceSinkDesc(C.Structure):
                 ("loop_forever", C.c_int32), ("agent_eyesight_range", C.c_double)]
 
 
+class MeshDesc(C.Structure):
+    _fields_ = [("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("halo_cells", C.c_uint32), ("flags", C.c_uint32),
+                ("device_ordinal", C.c_int32), ("rank", C.c_int32), ("n_ranks", C.c_int32),
+                ("density_per_cell", C.c_double), ("capacity_hint", C.c_uint64),
+                ("weights_xy", C.POINTER(C.c_double)), ("n_weights", C.c_size_t),
+                ("rccl_unique_id", C.POINTER(C.c_uint8))]
+
+
 class RouteMiss(C.Structure):
     _fields_ = [("id", C.c_uint64), ("hlp", C.c_uint32), ("slot", C.c_uint32), ("px", C.c_double),
                 ("py", C.c_double), ("tx", C.c_double), ("ty", C.c_double)]
@@ -188,6 +196,32 @@ SYMBOLS = {
     "cs_halo_exchange_rccl": (C.c_int, [C.c_void_p, C.c_int32]),
     "cs_allreduce_max_i32_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cs_tile_step_rccl": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
+    "cs_mesh_create": (C.c_void_p, [C.POINTER(GridDesc), C.POINTER(MeshDesc)]),
+    "cs_mesh_destroy": (None, [C.c_void_p]),
+    "cs_mesh_last_error": (C.c_char_p, [C.c_void_p]),
+    "cs_mesh_local_tiles": (C.c_size_t, [C.c_void_p]),
+    "cs_mesh_tile": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "cs_mesh_tile_rect": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "cs_mesh_register_zanlungo": (C.c_uint32, [C.c_void_p, C.POINTER(ZanlungoParams)]),
+    "cs_mesh_register_no_local_plan": (C.c_uint32, [C.c_void_p]),
+    "cs_mesh_register_hlp": (C.c_uint32, [C.c_void_p, C.POINTER(HlpDesc)]),
+    "cs_mesh_add_agents": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint32, C.c_uint32,
+                                      C.c_double, C.POINTER(C.c_uint64)]),
+    "cs_mesh_add_source_sink": (C.c_uint32, [C.c_void_p, C.POINTER(SourceSinkDesc)]),
+    "cs_mesh_remove_source_sink": (None, [C.c_void_p, C.c_uint32]),
+    "cs_mesh_remove_agent": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cs_mesh_event_recording": (None, [C.c_void_p, C.c_int]),
+    "cs_mesh_drain_events": (C.c_size_t, [C.c_void_p, C.POINTER(Event), C.c_size_t]),
+    "cs_mesh_step": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
+    "cs_mesh_synchronize": (C.c_int, [C.c_void_p]),
+    "cs_mesh_agent_count": (C.c_size_t, [C.c_void_p]),
+    "cs_mesh_read_agents": (C.c_size_t, [C.c_void_p, C.POINTER(AgentView), C.c_size_t]),
+    "cs_mesh_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cs_mesh_recut": (C.c_int, [C.c_void_p]),
+    "cs_mesh_query_radius_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cs_mesh_query_knn_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_size_t,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 

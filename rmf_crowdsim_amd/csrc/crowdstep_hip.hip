@@ -27,6 +27,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <array>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1104,3 +1106,5 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
 }
 
 }  // extern "C"
+
+#include "cs_mesh.hip.inc"

@@ -324,6 +324,27 @@ class EventListener:
 
 
 # ---- the simulation --------------------------------------------------------
+def source_sink_desc(source_sink, handle_of):
+    """cs_source_sink_desc of a SourceSink (source_sink.rs:36-60); handle_of(planner) -> its handle with the engine
+    (or mesh) the sink is being added to.  Returns (desc, what must stay alive while the sink does)."""
+    wps = np.ascontiguousarray(np.asarray(source_sink.waypoints, dtype=np.float64).reshape(-1, 2))
+    desc = _abi.SourceSinkDesc()
+    desc.source_x, desc.source_y = float(source_sink.source[0]), float(source_sink.source[1])
+    desc.radius_sink = float(source_sink.radius_sink)
+    keep = [source_sink.crowd_generator._fill(desc), wps]
+    desc.hlp = handle_of(source_sink.high_level_planner)
+    desc.lp = handle_of(source_sink.local_planner)
+    desc.waypoints_xy = wps.ctypes.data_as(C.POINTER(C.c_double))
+    desc.n_waypoints = wps.shape[0]
+    desc.loop_forever = 1 if source_sink.loop_forever else 0
+    desc.agent_eyesight_range = float(source_sink.agent_eyesight_range)
+    return desc, keep
+
+
+AGENT_DTYPE = np.dtype([("id", "<u8"), ("x", "<f8"), ("y", "<f8"), ("vx", "<f8"), ("vy", "<f8"),
+                        ("next_waypoint", "<u8"), ("eyesight_range", "<f8")])
+
+
 class Simulation:
     """Simulation<LocationHash2D>, lib.rs:69-383, on one MI355X."""
 
@@ -429,17 +450,7 @@ class Simulation:
 
     def add_source_sink(self, source_sink):
         """lib.rs:159-161 -> handle"""
-        wps = np.ascontiguousarray(np.asarray(source_sink.waypoints, dtype=np.float64).reshape(-1, 2))
-        desc = _abi.SourceSinkDesc()
-        desc.source_x, desc.source_y = float(source_sink.source[0]), float(source_sink.source[1])
-        desc.radius_sink = float(source_sink.radius_sink)
-        keep = source_sink.crowd_generator._fill(desc)
-        desc.hlp = self._handle(source_sink.high_level_planner)
-        desc.lp = self._handle(source_sink.local_planner)
-        desc.waypoints_xy = wps.ctypes.data_as(C.POINTER(C.c_double))
-        desc.n_waypoints = wps.shape[0]
-        desc.loop_forever = 1 if source_sink.loop_forever else 0
-        desc.agent_eyesight_range = float(source_sink.agent_eyesight_range)
+        desc, keep = source_sink_desc(source_sink, self._handle)
         handle = self._lib.cs_add_source_sink(self._engine, C.byref(desc))
         if handle == 0xFFFFFFFF:
             raise self._err()
@@ -498,10 +509,7 @@ class Simulation:
         n = self._lib.cs_agent_count(self._engine)
         buf = (_abi.AgentView * max(n, 1))()
         got = self._lib.cs_read_agents(self._engine, buf, n)
-        arr = np.frombuffer(buf, dtype=np.dtype([
-            ("id", "<u8"), ("x", "<f8"), ("y", "<f8"), ("vx", "<f8"), ("vy", "<f8"),
-            ("next_waypoint", "<u8"), ("eyesight_range", "<f8")]), count=got)
-        return arr.copy()
+        return np.frombuffer(buf, dtype=AGENT_DTYPE, count=got).copy()
 
     @property
     def agents(self):

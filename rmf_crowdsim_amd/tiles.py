@@ -383,6 +383,204 @@ class LocalTileMesh(_TileBase):
         return sum(len(sim) for sim in self.engines)
 
 
+class _MeshRegistrar:
+    """Lets a planner's `_register(lib, engine)` register it with a mesh: cs_register_x(engine, ...) becomes
+    cs_mesh_register_x(mesh, ...)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        if name.startswith("cs_register_") and hasattr(self._lib, "cs_mesh_register_" + name[len("cs_register_"):]):
+            return getattr(self._lib, "cs_mesh_register_" + name[len("cs_register_"):])
+        if name == "cs_last_error":
+            return self._lib.cs_mesh_last_error
+        raise AttributeError(f"{name}: not available on a mesh (host local planners go through single engines)")
+
+
+class NativeTileMesh:
+    """A crowd cut into tiles behind the C ABI's mesh handle (cs_mesh_*, include/crowdstep.h): layout, tile engines,
+    halo buffers, exchange, spawn flags, route misses, re-cuts and merged queries all live in the library
+    (csrc/cs_mesh.hip.inc); this class only converts arguments.  In-process form (every tile on one device),
+    the same interface as LocalTileMesh, whose Python orchestration it replaces; with `rccl_unique_id` (bytes from
+    Simulation.rccl_unique_id() on one rank, passed around by the host) the distributed form: this rank's tile only."""
+
+    def __init__(self, spatial_index, tiles, halo_cells, device=0, density_per_cell=16.0, flags=0, weights=None,
+                 capacity_hint=0, library=None, rank=0, n_ranks=1, rccl_unique_id=None):
+        import ctypes as C
+        from . import _native
+        from .simulation import CrowdSimError
+        self._C, self._err_cls = C, CrowdSimError
+        self._lib = library or _native.load()
+        desc = _abi.MeshDesc()
+        desc.tiles_x, desc.tiles_y = int(tiles[0]), int(tiles[1])
+        desc.halo_cells, desc.flags, desc.device_ordinal = int(halo_cells), int(flags), int(device)
+        desc.rank, desc.n_ranks = int(rank), int(n_ranks)
+        uid = None
+        if rccl_unique_id is not None:  # the distributed form: one tile per rank, halo records over RCCL
+            uid = (C.c_uint8 * len(rccl_unique_id)).from_buffer_copy(bytes(rccl_unique_id))
+            desc.rccl_unique_id = C.cast(uid, C.POINTER(C.c_uint8))
+        desc.density_per_cell, desc.capacity_hint = float(density_per_cell), int(capacity_hint)
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64).reshape(-1, 2))
+            desc.weights_xy, desc.n_weights = w.ctypes.data_as(C.POINTER(C.c_double)), len(w)
+        grid = spatial_index._desc()
+        self._mesh = self._lib.cs_mesh_create(C.byref(grid), C.byref(desc))
+        if not self._mesh:
+            raise CrowdSimError("cs_mesh_create failed: " + self._lib.cs_mesh_last_error(None).decode())
+        self._registrar = _MeshRegistrar(self._lib)
+        self._handles, self._alive, self._listeners = {}, [], []
+        self.last_report = None
+        self.shape = (desc.tiles_x, desc.tiles_y)
+
+    def __del__(self):
+        if getattr(self, "_mesh", None):
+            self._lib.cs_mesh_destroy(self._mesh)
+            self._mesh = None
+
+    def _err(self):
+        return self._err_cls(self._lib.cs_mesh_last_error(self._mesh).decode())
+
+    def _handle(self, planner):
+        key = id(planner)
+        if key not in self._handles:
+            handle = planner._register(self._registrar, self._mesh)
+            if handle == 0xFFFFFFFF:
+                raise self._err()
+            self._handles[key] = handle
+            self._alive.append(planner)
+        return self._handles[key]
+
+    def _dispatch(self):
+        if not self._listeners:
+            return
+        buf = (_abi.Event * 4096)()
+        while True:
+            n = self._lib.cs_mesh_drain_events(self._mesh, buf, len(buf))
+            for i in range(n):
+                for listener in self._listeners:
+                    if buf[i].kind == _abi.CS_EVENT_SPAWNED:
+                        listener.agent_spawned(np.array([buf[i].x, buf[i].y]), int(buf[i].id))
+                    elif buf[i].kind == _abi.CS_EVENT_DESTROYED:
+                        listener.agent_destroyed(int(buf[i].id))
+            if n < len(buf):
+                break
+
+    def add_agents(self, positions, high_level_planner, local_planner, eyesight):
+        C = self._C
+        pts = np.ascontiguousarray(np.asarray(positions, dtype=np.float64).reshape(-1, 2))
+        ids = np.zeros(len(pts), dtype=np.uint64)
+        rc = self._lib.cs_mesh_add_agents(self._mesh, pts.ctypes.data_as(C.POINTER(C.c_double)), len(pts),
+                                          self._handle(high_level_planner), self._handle(local_planner), float(eyesight),
+                                          ids.ctypes.data_as(C.POINTER(C.c_uint64)))
+        self._dispatch()
+        if rc != 0:
+            raise self._err()
+        return [int(i) for i in ids]
+
+    def add_source_sink(self, source_sink):
+        from .simulation import source_sink_desc
+        desc, keep = source_sink_desc(source_sink, self._handle)
+        handle = self._lib.cs_mesh_add_source_sink(self._mesh, self._C.byref(desc))
+        if handle == 0xFFFFFFFF:
+            raise self._err()
+        self._alive.append((source_sink, keep))
+        return handle
+
+    def remove_source_sink(self, handle):
+        self._lib.cs_mesh_remove_source_sink(self._mesh, int(handle))
+
+    def add_event_listener(self, listener):
+        self._listeners.append(listener)
+        self._lib.cs_mesh_event_recording(self._mesh, 1)
+
+    def remove_agents(self, agent):
+        rc = self._lib.cs_mesh_remove_agent(self._mesh, int(agent))
+        self._dispatch()
+        if rc != 0:
+            raise self._err()
+
+    def step(self, dur, report=True):
+        rep = _abi.StepReport()
+        need = report or bool(self._listeners)
+        rc = self._lib.cs_mesh_step(self._mesh, float(dur), self._C.byref(rep) if need else None)
+        if need:
+            self.last_report = rep.as_dict()
+        self._dispatch()
+        if rc != 0:
+            raise self._err()
+
+    def synchronize(self):
+        if self._lib.cs_mesh_synchronize(self._mesh) != 0:
+            raise self._err()
+
+    def recut(self):
+        if self._lib.cs_mesh_recut(self._mesh) != 0:
+            raise self._err()
+        return self.tile_counts()
+
+    def tile_counts(self):
+        n = self._lib.cs_mesh_local_tiles(self._mesh)
+        out = np.zeros(n, dtype=np.uint64)
+        self._lib.cs_mesh_tile_counts(self._mesh, out.ctypes.data_as(self._C.POINTER(self._C.c_uint64)))
+        return out.astype(np.int64).reshape(self.shape) if n == self.shape[0] * self.shape[1] else out.astype(np.int64)
+
+    def tile_rects(self):
+        n = self._lib.cs_mesh_local_tiles(self._mesh)
+        out = np.zeros((n, 4), dtype=np.uint32)
+        for k in range(n):
+            self._lib.cs_mesh_tile_rect(self._mesh, k, out[k].ctypes.data_as(self._C.POINTER(self._C.c_uint32)))
+        return out
+
+    def read_agents(self):
+        from .simulation import AGENT_DTYPE
+        self.synchronize()
+        n = self._lib.cs_mesh_agent_count(self._mesh)
+        buf = (_abi.AgentView * max(n, 1))()
+        got = self._lib.cs_mesh_read_agents(self._mesh, buf, n)
+        if got == self._C.c_size_t(-1).value:
+            raise self._err()
+        return np.frombuffer(buf, dtype=AGENT_DTYPE, count=got).copy()
+
+    def __len__(self):
+        return int(self._lib.cs_mesh_agent_count(self._mesh))
+
+    def get_neighbours_in_radius_batch(self, radii, positions):
+        C = self._C
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float64).reshape(-1, 2))
+        n = len(pos)
+        rad = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float64), (n,)))
+        cap = 64
+        while True:
+            ids, counts = np.zeros((n, cap), dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+            if self._lib.cs_mesh_query_radius_batch(self._mesh, n, pos.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    rad.ctypes.data_as(C.POINTER(C.c_double)), cap,
+                                                    ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                    counts.ctypes.data_as(C.POINTER(C.c_uint64))) != 0:
+                raise self._err()
+            if n == 0 or counts.max() <= cap:
+                return [[int(v) for v in ids[i, :int(counts[i])]] for i in range(n)]
+            cap = int(counts.max())
+
+    def get_neighbours_in_radius(self, radius, position):
+        return self.get_neighbours_in_radius_batch([radius], [position])[0]
+
+    def get_nearest_neighbours_batch(self, k, positions):
+        C = self._C
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.float64).reshape(-1, 2))
+        n, k = len(pos), int(k)
+        ids, counts = np.zeros((n, max(k, 1)), dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        if self._lib.cs_mesh_query_knn_batch(self._mesh, n, pos.ctypes.data_as(C.POINTER(C.c_double)), k,
+                                             ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             counts.ctypes.data_as(C.POINTER(C.c_uint64))) != 0:
+            raise self._err()
+        return [[int(v) for v in ids[i, :int(counts[i])]] for i in range(n)]
+
+    def get_nearest_neighbours(self, k, position):
+        return self.get_nearest_neighbours_batch(k, [position])[0]
+
+
 def exchange_axis(dist, layout, index, bufs, axis, op_cache=None):
     """One phase of the exchange for the tile `index` = this rank: post the sends of this axis
     and the matching receives as one batch (P2P over xGMI with the nccl/RCCL backend).  With

@@ -61,6 +61,30 @@ pub struct cs_engine {
     _private: [u8; 0],
 }
 
+/// Opaque handle of a crowd cut into spatial tiles (`struct cs_mesh`).
+#[repr(C)]
+pub struct cs_mesh {
+    _private: [u8; 0],
+}
+
+/// How to cut and place a mesh (cs_mesh_create)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cs_mesh_desc {
+    pub tiles_x: u32,
+    pub tiles_y: u32,
+    pub halo_cells: u32,
+    pub flags: u32,
+    pub device_ordinal: i32,
+    pub rank: i32,
+    pub n_ranks: i32,
+    pub density_per_cell: f64,
+    pub capacity_hint: u64,
+    pub weights_xy: *const f64,
+    pub n_weights: usize,
+    pub rccl_unique_id: *const u8,
+}
+
 /// LocationHash2D::new(width, height, cell_size, offset), location_hash_2d.rs:33-51
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -271,4 +295,28 @@ extern "C" {
     pub fn cs_halo_exchange_rccl(e: *mut cs_engine, axis: i32) -> c_int;
     pub fn cs_allreduce_max_i32_rccl(e: *mut cs_engine, values_dev: *mut c_int, n: usize) -> c_int;
     pub fn cs_tile_step_rccl(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
+
+    pub fn cs_mesh_create(grid: *const cs_grid_desc, desc: *const cs_mesh_desc) -> *mut cs_mesh;
+    pub fn cs_mesh_destroy(m: *mut cs_mesh);
+    pub fn cs_mesh_last_error(m: *const cs_mesh) -> *const c_char;
+    pub fn cs_mesh_local_tiles(m: *const cs_mesh) -> usize;
+    pub fn cs_mesh_tile(m: *mut cs_mesh, local_index: usize) -> *mut cs_engine;
+    pub fn cs_mesh_tile_rect(m: *const cs_mesh, local_index: usize, rect4: *mut u32) -> c_int;
+    pub fn cs_mesh_register_zanlungo(m: *mut cs_mesh, p: *const cs_zanlungo_params) -> u32;
+    pub fn cs_mesh_register_no_local_plan(m: *mut cs_mesh) -> u32;
+    pub fn cs_mesh_register_hlp(m: *mut cs_mesh, d: *const cs_hlp_desc) -> u32;
+    pub fn cs_mesh_add_agents(m: *mut cs_mesh, xy: *const f64, n: usize, hlp: u32, lp: u32, eyesight: f64, out_ids: *mut u64) -> c_int;
+    pub fn cs_mesh_add_source_sink(m: *mut cs_mesh, d: *const cs_source_sink_desc) -> u32;
+    pub fn cs_mesh_remove_source_sink(m: *mut cs_mesh, handle: u32);
+    pub fn cs_mesh_remove_agent(m: *mut cs_mesh, id: u64) -> c_int;
+    pub fn cs_mesh_event_recording(m: *mut cs_mesh, on: c_int);
+    pub fn cs_mesh_drain_events(m: *mut cs_mesh, out: *mut cs_event, cap: usize) -> usize;
+    pub fn cs_mesh_step(m: *mut cs_mesh, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
+    pub fn cs_mesh_synchronize(m: *mut cs_mesh) -> c_int;
+    pub fn cs_mesh_agent_count(m: *mut cs_mesh) -> usize;
+    pub fn cs_mesh_read_agents(m: *mut cs_mesh, out: *mut cs_agent_view, cap: usize) -> usize;
+    pub fn cs_mesh_tile_counts(m: *mut cs_mesh, out_per_local_tile: *mut u64) -> c_int;
+    pub fn cs_mesh_recut(m: *mut cs_mesh) -> c_int;
+    pub fn cs_mesh_query_radius_batch(m: *mut cs_mesh, n: usize, xy: *const f64, radius: *const f64, cap_per_query: usize, out_ids: *mut u64, out_counts: *mut u64) -> c_int;
+    pub fn cs_mesh_query_knn_batch(m: *mut cs_mesh, n: usize, xy: *const f64, k: usize, out_ids: *mut u64, out_counts: *mut u64) -> c_int;
 }

@@ -37,11 +37,13 @@ pub mod highlevel_planners;
 pub mod local_planners;
 pub mod source_sink;
 pub mod spatial_index;
+pub mod tiled;
 
 pub use crate::highlevel_planners::{DeviceHighLevelPlan, HighLevelPlanner};
 pub use crate::local_planners::{DeviceLocalPlan, LocalPlanner, NoLocalPlan, Zanlungo};
 pub use crate::source_sink::{CrowdGenerator, MonotonicCrowd, PoissonCrowd, SeededPoissonCrowd, SourceSink};
 pub use crate::spatial_index::{LocationHash2D, SpatialIndex};
+pub use crate::tiled::{Placement, TiledSimulation};
 
 /// lib.rs:22-33
 pub trait EventListener {

@@ -137,13 +137,37 @@ static void test_user_local_planner() {
   CHECK(std::hypot(sim.agents.at(2).position.x - 50.0, sim.agents.at(2).position.y - 50.1) < 1e-5);
 }
 
+// The reference's source-sink test on a 2 x 2 tile mesh (TiledSimulation over cs_mesh_*): same populations, same events
+static void test_event_listener_source_sink_api_on_a_mesh() {
+  TiledSimulation sim(LocationHash2D(1000.0, 1000.0, 20.0, Point{-500.0, -500.0}), 2, 2, 1);
+  auto listener = std::make_shared<MockEventListener>();
+  sim.add_event_listener(listener);
+  auto ss = std::make_shared<SourceSink>();
+  ss->source = Vec2f{-10.0, 0.0};           // the lane crosses the cut at x = 0
+  ss->waypoints = {Vec2f{10.0, 0.0}};
+  ss->radius_sink = 1.0;
+  ss->crowd_generator = std::make_shared<MonotonicCrowd>(1.0);
+  ss->high_level_planner = std::make_shared<StubHighLevelPlan>(Vec2f{1.0, 0.0});
+  ss->local_planner = std::make_shared<NoLocalPlan>();
+  ss->agent_eyesight_range = 5.0;
+  ss->loop_forever = false;
+  sim.add_source_sink(ss);
+  for (std::size_t steps = 0; steps < 40; ++steps) {
+    CHECK(sim.agents.size() == (steps < 20 ? steps : 20));
+    CHECK(listener->added.size() == steps);
+    CHECK(listener->removed.size() == (steps < 20 ? 0 : steps - 20));
+    sim.step(std::chrono::duration<double>(1.0));
+  }
+}
+
 int main() {
+  test_event_listener_source_sink_api_on_a_mesh();
   test_user_local_planner();
   test_snapshots();
   test_step_integration();
   test_event_listener_source_sink_api();
   test_index_out_of_bounds_is_an_error();
   test_viz_scene();
-  std::printf("6 passed\n");
+  std::printf("7 passed\n");
   return 0;
 }

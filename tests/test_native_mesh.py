@@ -1,0 +1,180 @@
+"""The multi-tile crowd behind the C ABI's mesh handle (cs_mesh_*, csrc/cs_mesh.hip.inc; review of round 2:
+layout, capacities, re-cuts, route-miss and query merging lived only in Python).  NativeTileMesh is a thin binding;
+what it drives must equal the single engine bit for bit, like the Python orchestration it replaces (LocalTileMesh,
+tests/test_gpu_tiles.py, whose scenes are reused here).
+
+CPU: the binding against the ORACLE's cs_mesh_* (one reference simulation whatever the tiling): the plumbing.
+"""
+import numpy as np
+import pytest
+
+from oracle_sim import OracleSimulation, load_oracle
+from rmf_crowdsim_amd import (LocationHash2D, NoLocalPlan, Simulation, StubHighLevelPlan, Zanlungo, scenes)
+from rmf_crowdsim_amd.tiles import LocalTileMesh, NativeTileMesh
+from test_gpu_tiles import _multi_leg_scene, _sink_scene
+
+
+class Heard:
+    def __init__(self):
+        self.added, self.removed = [], []
+
+    def agent_spawned(self, position, agent):
+        self.added.append(agent)
+
+    def agent_destroyed(self, agent):
+        self.removed.append(agent)
+
+
+def test_binding_against_the_oracles_mesh():
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    mesh = NativeTileMesh(LocationHash2D(**grid), (2, 2), 1, library=load_oracle("f64"))
+    ora = OracleSimulation(LocationHash2D(**grid))
+    heard = Heard()
+    mesh.add_event_listener(heard)
+    for t in (mesh, ora):
+        _sink_scene(t)
+        t.add_agents([(30.0, 30.0), (31.0, 30.5)], StubHighLevelPlan((0.1, 0.0)), NoLocalPlan(), 2.0)
+    for k in range(120):
+        mesh.step(0.05)
+        ora.step(0.05)
+    mesh.remove_agents(1)
+    ora.remove_agents(1)
+    a, b = mesh.read_agents(), ora.read_agents()
+    assert len(a) > 20 and a.tobytes() == b.tobytes() and len(mesh) == len(ora)
+    assert heard.added[:2] == [0, 1] and 1 in heard.removed and len(heard.added) == int(a["id"].max()) + 1
+    assert mesh.get_neighbours_in_radius(3.0, (30.0, 30.0)) == ora.get_neighbours_in_radius(3.0, (30.0, 30.0))
+    assert mesh.get_nearest_neighbours(2, (30.0, 30.0)) == ora.get_nearest_neighbours(2, (30.0, 30.0))
+    with pytest.raises(Exception):
+        NativeTileMesh(LocationHash2D(**grid), (0, 2), 1, library=load_oracle("f64"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles,halo,cell", [((2, 2), 1, 2.0), ((3, 1), 1, 2.0), ((2, 3), 2, 1.0)])
+def test_creeping_crowd_on_a_native_mesh_matches_engine_and_python_mesh(tiles, halo, cell):
+    pts, grid, extent, group = scenes.uniform_crowd(40000, seed=13, cell_size=cell)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    runs = []
+    for make in (lambda: Simulation(LocationHash2D(**grid)),
+                 lambda: NativeTileMesh(LocationHash2D(**grid), tiles, halo, density_per_cell=4.0 * cell * cell),
+                 lambda: LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=halo, density_per_cell=4.0 * cell * cell)):
+        t = make()
+        scenes.add_walking_crowd(t, pts, group, lp, 2.0)   # 6.5 cm per step: agents migrate over the cuts
+        for k in range(40):
+            t.step(0.05, report=(k % 16 == 0))
+        runs.append(t.read_agents())
+    assert len(runs[0]) == 40000 and runs[0].tobytes() == runs[1].tobytes() == runs[2].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles,listen", [((2, 2), False), ((3, 1), True)])
+def test_source_sinks_on_a_native_mesh(tiles, listen):
+    """Spawn flags OR-ed over the tiles in the library: on the device while nobody listens, through the host with a
+    listener or a report; ids, events and positions as the single engine's."""
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    single, mesh = Simulation(LocationHash2D(**grid)), NativeTileMesh(LocationHash2D(**grid), tiles, 1)
+    heard_s, heard_m = Heard(), Heard()
+    if listen:
+        single.add_event_listener(heard_s)
+        mesh.add_event_listener(heard_m)
+    for t in (single, mesh):
+        _sink_scene(t)
+    for k in range(800):
+        with_report = k in (250, 251, 500)
+        single.step(0.05, report=with_report)
+        mesh.step(0.05, report=with_report)
+        if with_report:
+            assert {key: single.last_report[key] for key in ("n_agents", "n_spawned", "n_destroyed")} == \
+                   {key: mesh.last_report[key] for key in ("n_agents", "n_spawned", "n_destroyed")}
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and a["id"].max() > 300 and a.tobytes() == b.tobytes()
+    if listen:  # every spawn and removal heard once (per-tile order: sort)
+        assert sorted(heard_s.added) == sorted(heard_m.added) and sorted(heard_s.removed) == sorted(heard_m.removed)
+        assert len(heard_m.removed) > 100
+    victim = int(a["id"][5])
+    single.remove_agents(victim)
+    mesh.remove_agents(victim)
+    with pytest.raises(Exception, match="unknown agent id"):
+        mesh.remove_agents(10 ** 9)
+    for _ in range(20):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+
+
+@pytest.mark.gpu
+def test_multi_leg_route_followers_on_a_native_mesh():
+    """Route-cache misses of all tiles merged in agent order and planned by every tile, inside cs_mesh_step."""
+    grid = dict(width=160.0, height=160.0, cell_size=2.0, offset=(0.0, 0.0))
+    single, mesh = Simulation(LocationHash2D(**grid)), NativeTileMesh(LocationHash2D(**grid), (2, 2), 1)
+    r_single, r_mesh = (_multi_leg_scene(t, NoLocalPlan()) for t in (single, mesh))
+    for k in range(700):
+        single.step(0.1, report=False)
+        mesh.step(0.1, report=False)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and (a["next_waypoint"] == 1).sum() > 20 and a.tobytes() == b.tobytes()
+    assert len(r_mesh.calls) == 4 * len(r_single.calls) >= 4 * 32   # every tile planned the same routes
+
+
+@pytest.mark.gpu
+def test_recut_and_queries_on_a_native_mesh():
+    """configs[4] in miniature: weighted cuts at creation, a re-cut of the running crowd in the library, merged
+    radius and k-NN queries; same bits and same lists as the single engine throughout."""
+    from rmf_crowdsim_amd import _abi
+    n = 120000
+    pts, grid, extent, group = scenes.hotspot_crowd(n, seed=11, cell_size=2.0, margin=10.0)
+    grid = dict(grid, width=grid["width"] + 60.0, height=grid["height"] + 60.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    single = Simulation(LocationHash2D(**grid), flags=_abi.CS_CFG_DENSE)
+    even = NativeTileMesh(LocationHash2D(**grid), (4, 2), 1, density_per_cell=60.0, flags=_abi.CS_CFG_DENSE)
+    cut = NativeTileMesh(LocationHash2D(**grid), (4, 2), 1, density_per_cell=60.0, flags=_abi.CS_CFG_DENSE, weights=pts)
+    for t in (single, even, cut):
+        scenes.add_walking_crowd(t, pts, group, lp, 2.0, creep=scenes.CREEP_SPEED * 0.1)
+        for _ in range(5):
+            t.step(0.05, report=False)
+    before, weighted = even.tile_counts(), cut.tile_counts()
+    assert before.sum() == weighted.sum() == n
+    assert before.max() / before.mean() > 1.25 and weighted.max() / weighted.mean() <= 1.2
+    ref = single.read_agents()
+    assert ref.tobytes() == even.read_agents().tobytes() == cut.read_agents().tobytes()
+    after = even.recut()
+    print(f"native recut: max/mean {before.max() / before.mean():.2f} -> {after.max() / after.mean():.3f} "
+          f"(cuts at creation: {weighted.max() / weighted.mean():.3f})")
+    assert after.sum() == n and after.max() / after.mean() <= 1.2
+    assert ref.tobytes() == even.read_agents().tobytes()
+    rng = np.random.default_rng(8)
+    q = rng.uniform(10.0, 10.0 + extent, (100, 2))
+    radii = rng.choice([0.5, 2.0, 6.0, 15.0], 100)
+    want = single.query_radius_batch(radii, q)
+    assert even.get_neighbours_in_radius_batch(radii, q) == want and sum(len(x) for x in want) > 3000
+    assert even.get_nearest_neighbours_batch(7, q[:40]) == single.query_knn_batch(7, q[:40])
+    for t in (single, even):
+        for _ in range(60):
+            t.step(0.05, report=False)
+    assert single.read_agents().tobytes() == even.read_agents().tobytes()
+
+
+@pytest.mark.gpu
+def test_distributed_form_with_one_rank():
+    """The distributed form of the mesh (a tile per rank, halo records over RCCL from the engine, the whole step one
+    call: cs_tile_step_rccl) with the one rank a one-GPU box allows: a 1 x 1 mesh on a communicator of one.  Device
+    path, host path (a report), source-sinks, a removal: the single engine's bits."""
+    grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
+    single = Simulation(LocationHash2D(**grid))
+    uid = single.rccl_unique_id()
+    mesh = NativeTileMesh(LocationHash2D(**grid), (1, 1), 1, rccl_unique_id=uid, rank=0, n_ranks=1)
+    for t in (single, mesh):
+        _sink_scene(t)
+    for k in range(400):
+        with_report = k in (150, 151)
+        single.step(0.05, report=with_report)
+        mesh.step(0.05, report=with_report)
+    a, b = single.read_agents(), mesh.read_agents()
+    assert len(a) > 100 and a.tobytes() == b.tobytes()
+    single.remove_agents(int(a["id"][3]))
+    mesh.remove_agents(int(a["id"][3]))
+    for _ in range(10):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+    with pytest.raises(Exception, match="re-cut by its host"):
+        mesh.recut()
