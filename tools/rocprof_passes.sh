@@ -6,6 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+# the chip's issue rate per instruction class (what the step kernel's instruction counts are priced against)
+[ -x tools/valu_ceiling ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/valu_ceiling tools/valu_ceiling.hip
+timeout -k 10 200 tools/valu_ceiling > $out/valu_ceiling.json || echo "valu_ceiling failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py $args > $out/trace_bench.json 2> $out/trace.err || { echo trace failed; tail -5 $out/trace.err; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $out/pmc1 -o pmc1 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc1.err || { echo pmc1 failed; tail -5 $out/pmc1.err; }
 timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INST_LEVEL_LDS -d $out/pmc2 -o pmc2 --output-format csv -- python3 bench.py $args > /dev/null 2> $out/pmc2.err || { echo pmc2 failed; tail -5 $out/pmc2.err; }
