@@ -139,6 +139,9 @@ def main():
                          "configuration, BASELINE.json configs[2]: 1M agents, 4 x 2 tiles on 8 GPUs); weak: every rank "
                          "adds --agents agents to one crowd.  With N > 1 the other mode is timed as well and reported "
                          "under `weak_scaled` / `strong_scaled`")
+    ap.add_argument("--watchdog", type=float, default=420.0,
+                    help="N > 1: seconds a rank may spend in one phase before it reports where it is stuck and exits "
+                         "(0 = off)")
     ap.add_argument("--no-second-scaling-leg", action="store_true",
                     help="N > 1: skip the second run in the other scaling mode")
     ap.add_argument("--eyesight", type=float, default=2.0)
@@ -207,9 +210,41 @@ def main():
         args.scaling = "strong"
     ctx = dict(torch=torch, dist=dist, rank=rank, world=world, device=device, backend=backend)
 
+    # N > 1: the first run of this code over RCCL with real peers may be the driver's.  A rank that sits in one
+    # phase for --watchdog seconds says where and leaves; if the headline leg is already measured (the stall is in
+    # the optional second leg), rank 0 prints its line first, so the measurement is not lost with the extra.
+    progress = {"phase": "headline leg (" + args.scaling + " scaling)", "line": None}
+    watchdog = None
+    if world > 1 and args.watchdog > 0:
+        import threading
+
+        def expired():
+            print(f"bench: rank {rank} made no progress for {args.watchdog:.0f} s in: {progress['phase']}", file=sys.stderr,
+                  flush=True)
+            if rank == 0 and progress["line"] is not None:
+                print(progress["line"], flush=True)
+            os._exit(0 if (progress["line"] is not None or progress.get("printed")) else 3)
+
+        def arm(phase):
+            nonlocal watchdog
+            if watchdog is not None:
+                watchdog.cancel()
+            progress["phase"] = phase
+            watchdog = threading.Timer(args.watchdog, expired)
+            watchdog.daemon = True
+            watchdog.start()
+        arm(progress["phase"])
+    else:
+        def arm(phase):
+            progress["phase"] = phase
+
     main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
     other_leg = None
     if world > 1 and not args.no_second_scaling_leg:
+        line = dict(main_leg["line"]) if rank == 0 else {}
+        line["second_scaling_leg"] = "did not finish"
+        progress["line"] = json.dumps(line)  # (on every rank: they all leave with 0 once the headline stands)
+        arm("second leg (the other scaling mode)")
         # the other scaling mode beside the headline (weak: N x --agents agents in one crowd)
         other = "weak" if args.scaling == "strong" else "strong"
         leg = run_leg(args, ctx, other, min(args.steps, 100), min(args.warmup, 10), 30, headline=False)
@@ -222,6 +257,8 @@ def main():
         if other_leg:
             out[other_leg["scaling"] + "_scaled"] = other_leg
         print(json.dumps(out), flush=True)
+    progress["line"], progress["printed"] = None, True
+    arm("shutdown")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

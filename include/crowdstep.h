@@ -490,6 +490,8 @@ int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
  *   rccl_unique_id given  one tile per rank (n_ranks = tiles_x * tiles_y, also 1 x 1 with one rank), rank = tile index = tx * tiles_y + ty, halo records over RCCL from the
  *                  engine itself; cs_mesh_step and cs_mesh_remove_agent are then collective; re-cuts and
  *                  spatial queries across ranks stay with the host (cs_tile_* / cs_query_*_batch per tile)
+ *                  Every rank passes the same grid and the same descriptor but for `rank` and the device: layout
+ *                  and halo capacities are computed from them on each rank and are not exchanged.
  * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics). */
 typedef struct cs_mesh cs_mesh;
 typedef struct cs_mesh_desc {

@@ -308,6 +308,10 @@ uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
   switch (which) {
     case CS_STAT_WINDOWS_OFF_LDS: return c.n_win_off_lds;
     case CS_STAT_WINDOWS_CHUNKED: return c.n_win_chunked;
+#ifdef CS_TILE_TRIPS
+    case 100: case 101: case 102: case 103: case 104: case 105: case 106: case 107: case 108: case 109: case 110: case 111:
+      return c.dbg[which - 100];
+#endif
     default: return 0;
   }
 }

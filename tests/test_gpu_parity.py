@@ -178,6 +178,31 @@ def test_tiny_relative_velocities_do_not_read_as_collisions(speed):
     assert np.allclose(a["x"], b["x"], atol=1e-6)
 
 
+@pytest.mark.parametrize("flags", [2, 1], ids=["tiled", "gather"])
+@pytest.mark.parametrize("vx", [1e-25, -1e-25, 1e-14, 0.0], ids=["approaching", "receding", "slow", "equal"])
+def test_overlapping_pairs_collide_now_whatever_their_relative_velocity(vx, flags):
+    """Two agents 0.15 m apart (collision distance R = 0.2 m): zanlungo.rs:61-73 answers t = 0 ("colliding
+    now": t0 < 0 < t1) for ANY relative velocity but an exactly zero one, also where f32 cannot represent
+    |rel_vel|^2 (the plain quadratic of the hot loops then says "no collision"; overlapping pairs take the
+    guarded form, ttc_pair_f32).  A third agent far from both keeps its wave company.  Same n_tti_zero, same
+    NaN / clamp pattern as the f64 oracle, in both kernels."""
+    out = []
+    for cls in (Simulation, OracleSimulation):
+        kw = dict(flags=flags) if cls is Simulation else {}
+        sim = cls(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)), **kw)
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        sim.add_agents([(50.0, 50.0)], StubHighLevelPlan((vx, 0.0)), lp, 2.0)
+        sim.add_agents([(50.15, 50.01)], StubHighLevelPlan((0.0, 0.0)), lp, 2.0)
+        sim.add_agents([(70.0, 70.0)], StubHighLevelPlan((0.0, 0.0)), lp, 2.0)
+        sim.step(1e-18)  # velocities are (0, 0) until the first step has set them
+        sim.step(1e-18)  # (a step so short that whoever is thrown at 1e15 m/s stays on the grid)
+        a = sim.read_agents()
+        out.append((sim.last_report["n_tti_zero"], sim.last_report["n_nonfinite"], np.isnan(a["vx"]).tolist(),
+                    np.isnan(a["vy"]).tolist(), (np.abs(a["vy"]) > 1e14).tolist()))
+    assert out[0] == out[1], out
+    assert out[1][0] == (0 if vx == 0.0 else 2)
+
+
 # ---- config 1: the visualiser's scene ---------------------------------------------------
 def test_viz_scene_literal_1000_steps():
     """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),

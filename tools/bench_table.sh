@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (under gpurun): tools/bench_table.sh <tag> -- the workloads of DESIGN.md section 8, one line each
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out/table_$tag
 line() { python -c "import json,sys; r=json.loads(sys.stdin.read()); c=r.get('creep_scene'); print('%-34s ms/step %.4f  value %.3g  k4_ms %.4f%s' % (sys.argv[1], r['ms_per_step'], r['value'], r['roofline']['kernel_ms'], ('  creep k4_ms %.4f' % c['kernel_ms']) if c else ''))" "$1"; }
 run() { name=$1; shift; timeout -k 10 200 python bench.py --no-cpu-baseline "$@" 2> gpurun_out/table_$tag/$name.err | tee gpurun_out/table_$tag/$name.json | line $name || { echo "$name failed"; tail -3 gpurun_out/table_$tag/$name.err; }; }
