@@ -494,11 +494,11 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         del stepper, sim
         c_sim, _, _ = build_crowd(Simulation, per_gpu, args.cell, args.eyesight, speed, workload="creep",
                                   device=device, stream=torch.cuda.current_stream().cuda_stream, capacity=per_gpu + 1024)
-        for _ in range(10):
-            c_sim.step(0.05, report=False)
+        for _ in range(max(10, warmup + clock_warmup)):  # the same untimed steps as the headline leg (the clocks
+            c_sim.step(0.05, report=False)                # have dropped while the host built this crowd)
         c_sim.synchronize()
         c_sim.profile_reset()
-        c_sim.profile_stride(2)
+        c_sim.profile_stride(4)
         c_sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
         torch.cuda.synchronize()
         c0 = time.perf_counter()
@@ -568,7 +568,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                 "valu_ceiling": ceiling,
                 "pmc_source": pmc_source,
                 "note": "HBM is the nominal bound of a neighbour gather; at ~31 neighbours per agent the kernel is "
-                        "bound by VALU issue and LDS latency (DESIGN.md section 4); traffic / valu_* are null unless a "
+                        "bound by instruction issue (DESIGN.md section 4, measured issue costs); traffic / valu_* are null unless a "
                         "PMC summary taken on exactly these sources and this workload is cached under profiles/",
             },
         }
@@ -593,9 +593,15 @@ def valu_ceiling():
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "valu_ceiling.json")) as f:
                 c = json.load(f)
-            c["source"] = f"profiles/{rnd}/valu_ceiling.json"
-            return c
-        except (OSError, ValueError):
+            pc = c.get("per_class", {})
+            at4 = lambda k: pc.get(k, {}).get("waves_per_simd_4")  # noqa: E731
+            # (the line carries the three classes' rates, not the table of fifty)
+            return {"source": f"profiles/{rnd}/valu_ceiling.json", "device": c.get("device"),
+                    "unit": "wave64 instructions per second, whole chip, 4 waves per SIMD",
+                    "fma_wave_insts_per_s": c["fma_wave_insts_per_s"],
+                    "half_rate_class_per_s": at4("v_cvt_f32_i32"), "quarter_rate_class_per_s": at4("v_sqrt_f32"),
+                    "one_wave_per_simd_fma_per_s": pc.get("v_fma_f32", {}).get("waves_per_simd_1")}
+        except (OSError, ValueError, KeyError):
             continue
     return None
 

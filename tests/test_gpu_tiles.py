@@ -123,6 +123,24 @@ def test_an_agent_that_outruns_the_border_launch_fails_the_step(monkeypatch):
         mesh.read_agents()
 
 
+def test_a_late_agent_fails_a_step_soon_and_without_a_readback(monkeypatch):
+    """A tile that nobody reads from looks at its error counters the blocking way every 32nd step only.  The step
+    kernel's first thread therefore also stores the cumulative error counters into pinned host memory (the second
+    word behind the slot bound), and a non-zero word makes the next cs_step read the counters: the late agent of
+    step 1 fails a step a few steps later, not 32 steps later and not only at the next read-back."""
+    from rmf_crowdsim_amd.simulation import CrowdSimError
+    monkeypatch.setenv("CS_TILE_SPLIT", "1")
+    pts, grid, extent, group = scenes.uniform_crowd(20000, seed=3, cell_size=2.0, margin=60.0)
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 1), halo_cells=3)
+    _populate(mesh, pts, group, [(90.0, 0.0), (90.0, 0.0)], Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+    done = 0
+    with pytest.raises(CrowdSimError, match="halo band"):
+        for _ in range(10):
+            mesh.step(0.05, report=False)
+            done += 1
+    assert 1 <= done <= 8
+
+
 def test_hotspot_crowd_with_weighted_cuts_matches_single_engine():
     """BASELINE.json configs[4] in miniature: clustered crowd (cells of up to ~45 agents, far more
     neighbours in sight than a neighbour list holds), tile cuts at the histogram quantiles."""
