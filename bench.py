@@ -40,11 +40,14 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave64 VALU instructions per second: 102
 
 def profile_key(workload_desc):
     """Identifies what a cached PMC summary (profiles/rNN/k4_traffic.json) was measured on: the
-    kernel sources, the compiler flags and the workload.  A summary with another key is stale."""
+    kernel sources (device code and the engine that configures and launches it; not the orchestration above the
+    engine: the mesh and the RCCL binding), the compiler flags and the workload.  A summary with another key is stale."""
     import hashlib
     from rmf_crowdsim_amd import _native
     h = hashlib.sha256()
     for name in sorted(os.listdir(_native.CSRC)):
+        if name in ("cs_mesh.hip.inc", "cs_rccl.hip.inc"):
+            continue
         with open(os.path.join(_native.CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     h.update(" ".join(_native.HIPCC_FLAGS).encode())

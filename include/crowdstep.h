@@ -488,12 +488,35 @@ int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
  * for bit on scenes that stay clear of the domain's edges (a tile's grid edges are strict).
  *   rccl_unique_id null   every tile in this process on ONE device (exchanges are device copies on a shared stream)
  *   rccl_unique_id given  one tile per rank (n_ranks = tiles_x * tiles_y, also 1 x 1 with one rank), rank = tile index = tx * tiles_y + ty, halo records over RCCL from the
- *                  engine itself; cs_mesh_step and cs_mesh_remove_agent are then collective; re-cuts and
- *                  spatial queries across ranks stay with the host (cs_tile_* / cs_query_*_batch per tile)
+ *                  engine itself; cs_mesh_step and cs_mesh_remove_agent are then collective; re-cuts, merged
+ *                  spatial queries and the route-cache misses of multi-leg sinks need a host_transport beside it
+ *                  (or stay with the host: cs_tile_* / cs_query_*_batch / cs_route_misses per tile)
+ *   host_transport given  the same one-tile-per-rank form over a transport of the host's (see above); with it
+ *                  cs_mesh_recut, cs_mesh_query_*_batch, cs_mesh_agent_count / cs_mesh_read_agents (the whole crowd
+ *                  on every rank) and multi-leg route followers work across ranks (all collective)
  *                  Every rank passes the same grid and the same descriptor but for `rank` and the device: layout
  *                  and halo capacities are computed from them on each rank and are not exchanged.
  * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics). */
 typedef struct cs_mesh cs_mesh;
+/* A transport the HOST brings (MPI, gloo, sockets) for a distributed mesh: instead of RCCL (rccl_unique_id null:
+ * the halo records and the spawn flags go through it, staged in pinned host memory), or beside it (both given:
+ * RCCL moves halos and flags, this moves what the RCCL form leaves to the host: route-cache misses of multi-leg
+ * sinks, re-cuts, merged queries).  Every buffer is host memory.  The calls are collective: every rank of the mesh
+ * makes them in the same order (the mesh does, if every rank makes the same cs_mesh_* calls).  0 = success.
+ *   exchange           n messages out and n in: send_host[k] (bytes[k] bytes) goes to rank peers[k], recv_host[k]
+ *                      takes bytes[k] bytes from rank peers[k].  send_tags[k] is the direction (0..7) the message
+ *                      leaves this rank in and travels with it; recv_tags[k] is the tag of the message expected
+ *                      (the peer's direction towards this rank), should a pair of ranks exchange several.
+ *   allreduce_max_i32  element-wise maximum over the ranks, in place
+ *   allgather          every rank contributes `bytes` bytes (the same number everywhere); `all` receives
+ *                      n_ranks * bytes, in rank order */
+typedef struct cs_mesh_host_transport {
+  void* user;
+  int (*exchange)(void* user, size_t n, const int32_t* peers, const int32_t* send_tags, const int32_t* recv_tags,
+                  const void* const* send_host, void* const* recv_host, const size_t* bytes);
+  int (*allreduce_max_i32)(void* user, int32_t* values, size_t n);
+  int (*allgather)(void* user, const void* mine, size_t bytes, void* all);
+} cs_mesh_host_transport;
 typedef struct cs_mesh_desc {
   uint32_t tiles_x, tiles_y;   /* 4 x 2 on 8 GPUs (BASELINE.json configs[2]); x = the index location_to_index
                                 * multiplies by the row stride (location_hash_2d.rs:59) */
@@ -506,6 +529,7 @@ typedef struct cs_mesh_desc {
   const double* weights_xy;    /* optional: n_weights positions; the cuts go to the quantiles of their */
   size_t n_weights;            /*   row / column histograms (a clustered crowd, configs[4]) */
   const uint8_t* rccl_unique_id; /* distributed form: CS_RCCL_UNIQUE_ID_BYTES from cs_rccl_unique_id on one rank */
+  const cs_mesh_host_transport* host_transport; /* distributed form without RCCL, or beside it (copied at creation) */
 } cs_mesh_desc;
 cs_mesh* cs_mesh_create(const cs_grid_desc* grid, const cs_mesh_desc* desc);
 void cs_mesh_destroy(cs_mesh*);
@@ -525,7 +549,7 @@ void cs_mesh_event_recording(cs_mesh*, int on);
 size_t cs_mesh_drain_events(cs_mesh*, cs_event* out, size_t cap);
 int cs_mesh_step(cs_mesh*, double dt_seconds, cs_step_report* report);            /* lib.rs:195-383 */
 int cs_mesh_synchronize(cs_mesh*);
-size_t cs_mesh_agent_count(cs_mesh*);
+size_t cs_mesh_agent_count(cs_mesh*);      /* the local tiles' agents; over all ranks with a host transport (collective) */
 size_t cs_mesh_read_agents(cs_mesh*, cs_agent_view* out, size_t cap);             /* ascending id; SIZE_MAX on error */
 int cs_mesh_tile_counts(cs_mesh*, uint64_t* out_per_local_tile);
 int cs_mesh_recut(cs_mesh*);

@@ -98,12 +98,24 @@ class SourceSinkDesc(C.Structure):
                 ("loop_forever", C.c_int32), ("agent_eyesight_range", C.c_double)]
 
 
+# cs_mesh_host_transport: a transport the host brings for a distributed mesh (host memory throughout)
+MeshExchangeFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                             C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+MeshAllreduceMaxFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_size_t)
+MeshAllgatherFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class MeshHostTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", MeshExchangeFn), ("allreduce_max_i32", MeshAllreduceMaxFn),
+                ("allgather", MeshAllgatherFn)]
+
+
 class MeshDesc(C.Structure):
     _fields_ = [("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("halo_cells", C.c_uint32), ("flags", C.c_uint32),
                 ("device_ordinal", C.c_int32), ("rank", C.c_int32), ("n_ranks", C.c_int32),
                 ("density_per_cell", C.c_double), ("capacity_hint", C.c_uint64),
                 ("weights_xy", C.POINTER(C.c_double)), ("n_weights", C.c_size_t),
-                ("rccl_unique_id", C.POINTER(C.c_uint8))]
+                ("rccl_unique_id", C.POINTER(C.c_uint8)), ("host_transport", C.POINTER(MeshHostTransport))]
 
 
 class RouteMiss(C.Structure):

@@ -398,15 +398,74 @@ class _MeshRegistrar:
         raise AttributeError(f"{name}: not available on a mesh (host local planners go through single engines)")
 
 
+class TorchHostTransport:
+    """cs_mesh_host_transport over torch.distributed (any backend that moves CPU tensors: gloo, mpi): the halo
+    records, the spawn flags and the gathers of a distributed cs_mesh through a transport the HOST brings instead of
+    (or beside) RCCL.  The library stages device data through pinned host memory; these callbacks only see host
+    pointers.  A host in another language passes its own three functions (MPI_Sendrecv / MPI_Allreduce /
+    MPI_Allgather would do)."""
+
+    def __init__(self, dist=None, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as tdist
+        self.dist, self.group, self.torch, self._C = dist or tdist, group, torch, C
+        self.failure = None
+
+        def view(ptr, nbytes, dtype=torch.uint8):
+            raw = (C.c_ubyte * nbytes).from_address(ptr)
+            return torch.frombuffer(raw, dtype=dtype)
+
+        def guard(fn):
+            def run(*args):
+                try:
+                    fn(*args)
+                    return 0
+                except Exception as err:  # (an exception must not cross the C frame)
+                    self.failure = err
+                    return 1
+            return run
+
+        def exchange(_user, n, peers, send_tags, recv_tags, send_host, recv_host, nbytes):
+            ops = []
+            for k in range(n):
+                if nbytes[k] == 0:
+                    continue
+                ops.append(self.dist.P2POp(self.dist.isend, view(send_host[k], nbytes[k]), int(peers[k]), self.group,
+                                           int(send_tags[k])))
+                ops.append(self.dist.P2POp(self.dist.irecv, view(recv_host[k], nbytes[k]), int(peers[k]), self.group,
+                                           int(recv_tags[k])))
+            if ops:
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()
+
+        def allreduce_max(_user, values, n):
+            if n:
+                t = view(C.addressof(values.contents), 4 * n, torch.int32)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+
+        def allgather(_user, mine, nbytes, everything):
+            if nbytes:
+                world = self.dist.get_world_size(self.group)
+                out = list(view(everything, nbytes * world).chunk(world))
+                self.dist.all_gather(out, view(mine, nbytes), group=self.group)
+
+        self._keep = (_abi.MeshExchangeFn(guard(exchange)), _abi.MeshAllreduceMaxFn(guard(allreduce_max)),
+                      _abi.MeshAllgatherFn(guard(allgather)))
+        self.struct = _abi.MeshHostTransport(None, *self._keep)
+
+
 class NativeTileMesh:
     """A crowd cut into tiles behind the C ABI's mesh handle (cs_mesh_*, include/crowdstep.h): layout, tile engines,
     halo buffers, exchange, spawn flags, route misses, re-cuts and merged queries all live in the library
     (csrc/cs_mesh.hip.inc); this class only converts arguments.  In-process form (every tile on one device),
     the same interface as LocalTileMesh, whose Python orchestration it replaces; with `rccl_unique_id` (bytes from
-    Simulation.rccl_unique_id() on one rank, passed around by the host) the distributed form: this rank's tile only."""
+    Simulation.rccl_unique_id() on one rank, passed around by the host) and / or `host_transport` (a
+    TorchHostTransport, or anything with a `.struct` of type _abi.MeshHostTransport) the distributed form: this
+    rank's tile only; with a host transport read_agents, len(), re-cuts and queries cover the whole crowd (collective)."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device=0, density_per_cell=16.0, flags=0, weights=None,
-                 capacity_hint=0, library=None, rank=0, n_ranks=1, rccl_unique_id=None):
+                 capacity_hint=0, library=None, rank=0, n_ranks=1, rccl_unique_id=None, host_transport=None):
         import ctypes as C
         from . import _native
         from .simulation import CrowdSimError
@@ -420,6 +479,9 @@ class NativeTileMesh:
         if rccl_unique_id is not None:  # the distributed form: one tile per rank, halo records over RCCL
             uid = (C.c_uint8 * len(rccl_unique_id)).from_buffer_copy(bytes(rccl_unique_id))
             desc.rccl_unique_id = C.cast(uid, C.POINTER(C.c_uint8))
+        self._host_transport = host_transport  # (the callbacks must outlive the mesh)
+        if host_transport is not None:
+            desc.host_transport = C.pointer(host_transport.struct)
         desc.density_per_cell, desc.capacity_hint = float(density_per_cell), int(capacity_hint)
         w = None
         if weights is not None:
@@ -440,7 +502,9 @@ class NativeTileMesh:
             self._mesh = None
 
     def _err(self):
-        return self._err_cls(self._lib.cs_mesh_last_error(self._mesh).decode())
+        why = self._lib.cs_mesh_last_error(self._mesh).decode()
+        cause = getattr(self._host_transport, "failure", None)
+        return self._err_cls(why + (f" ({cause!r})" if cause is not None else ""))
 
     def _handle(self, planner):
         key = id(planner)

@@ -178,3 +178,80 @@ def test_distributed_form_with_one_rank():
     assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
     with pytest.raises(Exception, match="re-cut by its host"):
         mesh.recut()
+
+
+# ---- the distributed form over a transport the HOST brings (cs_mesh_host_transport) ----------------------
+def _rank_host_transport(rank, world, port, out_path, kind, layout):
+    """One rank per tile, two processes sharing the GPU, torch.distributed / gloo as the host's transport: halo
+    records, spawn flags, route-cache misses, a re-cut, a removal and merged queries all go through cs_mesh_*."""
+    import os
+    import pickle
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_tiles import _TWO_RANK_GRID, _two_rank_scene
+    from rmf_crowdsim_amd.tiles import TorchHostTransport
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        side, dt = _TWO_RANK_GRID[kind]
+        grid = dict(width=side, height=side, cell_size=2.0, offset=(0.0, 0.0))
+        mesh = NativeTileMesh(LocationHash2D(**grid), layout, 2, device=0, rank=rank, n_ranks=world,
+                              host_transport=TorchHostTransport(dist))
+        _two_rank_scene(kind, mesh)
+        for k in range(400):
+            if k == 120 and kind == "sinks":
+                mesh.remove_source_sink(3)
+            if k == 260:
+                mesh.recut()  # collective: histograms and exported records through the host's allgather
+            mesh.step(dt, report=(k in (150, 151)))
+            if k == 200:  # the whole crowd is on every rank: everybody removes the same walker
+                mesh.remove_agents(int(mesh.read_agents()["id"].max()))
+        a = mesh.read_agents()
+        probes = [(side * 0.5, side * 0.5), (side * 0.25, side * 0.6), (side * 0.75, side * 0.4)]
+        near = mesh.get_neighbours_in_radius_batch([6.0, 9.0, 4.0], probes)
+        knn = mesh.get_nearest_neighbours_batch(5, probes)
+        counts = [None] * world
+        dist.all_gather_object(counts, int(mesh.tile_counts().sum()))
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                pickle.dump((a, near, knn, counts), f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,layout,port", [("sinks", (2, 1), 29741), ("legs", (1, 2), 29742)])
+def test_two_ranks_over_a_host_transport(tmp_path, kind, layout, port):
+    """The distributed cs_mesh over a transport of the host's (here torch.distributed / gloo: two ranks sharing the
+    one GPU): same bits as one engine after 400 steps with a removed sink, a removed agent and a re-cut on the way;
+    read_agents and the batch queries answer for the whole crowd on every rank."""
+    import pickle
+    import torch.multiprocessing as mp
+    from test_gpu_tiles import _TWO_RANK_GRID, _two_rank_scene
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "host_transport.pkl")
+    procs = [ctx.Process(target=_rank_host_transport, args=(r, 2, port, out, kind, layout)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    with open(out, "rb") as f:
+        both, near, knn, counts = pickle.load(f)
+    side, dt = _TWO_RANK_GRID[kind]
+    single = Simulation(LocationHash2D(side, side, 2.0, (0.0, 0.0)))
+    _two_rank_scene(kind, single)
+    for k in range(400):
+        if k == 120 and kind == "sinks":
+            single.remove_source_sink(3)
+        single.step(dt, report=False)
+        if k == 200:
+            single.remove_agents(int(single.read_agents()["id"].max()))
+    a = single.read_agents()
+    assert len(a) > 50 and a.tobytes() == both.tobytes()
+    assert sum(counts) == len(a) and min(counts) > 0
+    probes = [(side * 0.5, side * 0.5), (side * 0.25, side * 0.6), (side * 0.75, side * 0.4)]
+    assert near == single.get_neighbours_in_radius_batch([6.0, 9.0, 4.0], probes)
+    assert knn == single.get_nearest_neighbours_batch(5, probes)
