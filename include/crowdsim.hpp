@@ -365,14 +365,17 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
 // The same `Simulation`, cut into tiles_x x tiles_y spatial tiles: one tile engine per tile behind
 // the C ABI's mesh handle (cs_mesh_*: layout, halo exchange, spawn flags, route misses, re-cuts, merged queries all
 // in the library).  With `rccl_unique_id` (CS_RCCL_UNIQUE_ID_BYTES from cs_rccl_unique_id on one rank) the
-// distributed form: one tile per rank and GPU, `agents` then holds this rank's share.  Results equal Simulation's
-// bit for bit while nobody touches the domain's edges.
+// distributed form: one tile per rank and GPU, `agents` then holds this rank's share; with a `host_transport`
+// (three functions over MPI, sockets, ...: cs_mesh_host_transport) instead of or beside it, `agents`, re-cuts and the
+// queries cover the whole crowd on every rank.  Results equal Simulation's bit for bit while nobody touches the
+// domain's edges.
 class TiledSimulation {
  public:
   std::unordered_map<AgentId, Agent> agents;  // lib.rs:71, refreshed after every mutating call
 
   TiledSimulation(const LocationHash2D& index, uint32_t tiles_x, uint32_t tiles_y, uint32_t halo_cells, int device = 0,
-                  const uint8_t* rccl_unique_id = nullptr, int rank = 0, int n_ranks = 1, double density_per_cell = 16.0) {
+                  const uint8_t* rccl_unique_id = nullptr, int rank = 0, int n_ranks = 1, double density_per_cell = 16.0,
+                  const cs_mesh_host_transport* host_transport = nullptr) {
     cs_grid_desc g{index.width, index.height, index.cell_size, index.offset.x, index.offset.y};
     cs_mesh_desc d{};
     d.tiles_x = tiles_x;
@@ -383,6 +386,7 @@ class TiledSimulation {
     d.n_ranks = n_ranks;
     d.density_per_cell = density_per_cell;
     d.rccl_unique_id = rccl_unique_id;
+    d.host_transport = host_transport;
     mesh_ = cs_mesh_create(&g, &d);
     if (!mesh_) throw std::runtime_error(std::string("cs_mesh_create failed: ") + cs_mesh_last_error(nullptr));
   }

@@ -510,12 +510,16 @@ typedef struct cs_mesh cs_mesh;
  *   allreduce_max_i32  element-wise maximum over the ranks, in place
  *   allgather          every rank contributes `bytes` bytes (the same number everywhere); `all` receives
  *                      n_ranks * bytes, in rank order */
+typedef int (*cs_mesh_exchange_fn)(void* user, size_t n, const int32_t* peers, const int32_t* send_tags,
+                                   const int32_t* recv_tags, const void* const* send_host, void* const* recv_host,
+                                   const size_t* bytes);
+typedef int (*cs_mesh_allreduce_max_fn)(void* user, int32_t* values, size_t n);
+typedef int (*cs_mesh_allgather_fn)(void* user, const void* mine, size_t bytes, void* all);
 typedef struct cs_mesh_host_transport {
   void* user;
-  int (*exchange)(void* user, size_t n, const int32_t* peers, const int32_t* send_tags, const int32_t* recv_tags,
-                  const void* const* send_host, void* const* recv_host, const size_t* bytes);
-  int (*allreduce_max_i32)(void* user, int32_t* values, size_t n);
-  int (*allgather)(void* user, const void* mine, size_t bytes, void* all);
+  cs_mesh_exchange_fn exchange;
+  cs_mesh_allreduce_max_fn allreduce_max_i32;
+  cs_mesh_allgather_fn allgather;
 } cs_mesh_host_transport;
 typedef struct cs_mesh_desc {
   uint32_t tiles_x, tiles_y;   /* 4 x 2 on 8 GPUs (BASELINE.json configs[2]); x = the index location_to_index

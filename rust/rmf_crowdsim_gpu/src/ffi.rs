@@ -67,6 +67,19 @@ pub struct cs_mesh {
     _private: [u8; 0],
 }
 
+/// A transport the host brings for a distributed mesh (MPI, sockets, ...): host memory throughout, collective calls.
+pub type cs_mesh_exchange_fn = Option<unsafe extern "C" fn(user: *mut c_void, n: usize, peers: *const i32, send_tags: *const i32, recv_tags: *const i32, send_host: *const *const c_void, recv_host: *const *mut c_void, bytes: *const usize) -> c_int>;
+pub type cs_mesh_allreduce_max_fn = Option<unsafe extern "C" fn(user: *mut c_void, values: *mut i32, n: usize) -> c_int>;
+pub type cs_mesh_allgather_fn = Option<unsafe extern "C" fn(user: *mut c_void, mine: *const c_void, bytes: usize, all: *mut c_void) -> c_int>;
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cs_mesh_host_transport {
+    pub user: *mut c_void,
+    pub exchange: cs_mesh_exchange_fn,
+    pub allreduce_max_i32: cs_mesh_allreduce_max_fn,
+    pub allgather: cs_mesh_allgather_fn,
+}
+
 /// How to cut and place a mesh (cs_mesh_create)
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -83,6 +96,7 @@ pub struct cs_mesh_desc {
     pub weights_xy: *const f64,
     pub n_weights: usize,
     pub rccl_unique_id: *const u8,
+    pub host_transport: *const cs_mesh_host_transport,
 }
 
 /// LocationHash2D::new(width, height, cell_size, offset), location_hash_2d.rs:33-51

@@ -24,6 +24,10 @@ pub enum Placement {
     /// one tile per rank and GPU; `unique_id` comes from `ffi::cs_rccl_unique_id` on one rank and is passed
     /// around by the host (MPI, a file, a socket)
     Distributed { device: i32, rank: i32, n_ranks: i32, unique_id: [u8; ffi::CS_RCCL_UNIQUE_ID_BYTES] },
+    /// one tile per rank over a transport the host brings (`ffi::cs_mesh_host_transport`: three `extern "C"`
+    /// functions over MPI, sockets, ...; host memory throughout), instead of RCCL; with it re-cuts, merged queries,
+    /// `agents` of the whole crowd and multi-leg route followers work across ranks.  The struct must outlive the mesh.
+    HostTransport { device: i32, rank: i32, n_ranks: i32, transport: &'static ffi::cs_mesh_host_transport },
 }
 
 pub struct TiledSimulation {
@@ -52,6 +56,7 @@ impl TiledSimulation {
             weights_xy: std::ptr::null(),
             n_weights: 0,
             rccl_unique_id: std::ptr::null(),
+            host_transport: std::ptr::null(),
         };
         let id_cell; // keeps the unique id alive across the call
         match placement {
@@ -62,6 +67,12 @@ impl TiledSimulation {
                 desc.n_ranks = n_ranks;
                 id_cell = unique_id;
                 desc.rccl_unique_id = id_cell.as_ptr();
+            }
+            Placement::HostTransport { device, rank, n_ranks, transport } => {
+                desc.device_ordinal = device;
+                desc.rank = rank;
+                desc.n_ranks = n_ranks;
+                desc.host_transport = transport as *const ffi::cs_mesh_host_transport;
             }
         }
         let mesh = unsafe { ffi::cs_mesh_create(&grid, &desc) };

@@ -134,6 +134,57 @@ int main() {
   same();
   cs_mesh_destroy(mesh);
   cs_destroy(one);
+
+  // the distributed form over a transport the HOST brings, with the one rank a single process has: a loop-back
+  // transport (nobody to exchange with, an all-reduce of one, an all-gather of one) drives the same code the ranks of
+  // an MPI host would (tests/test_native_mesh.py runs it with two ranks over gloo)
+  static int calls[3] = {0, 0, 0};
+  cs_mesh_host_transport loop;
+  loop.user = calls;
+  loop.exchange = [](void* u, size_t n_msgs, const int32_t*, const int32_t*, const int32_t*, const void* const*, void* const*,
+                     const size_t*) -> int {
+    ++static_cast<int*>(u)[0];
+    return n_msgs == 0 ? 0 : 1;  // a 1 x 1 mesh has no neighbours
+  };
+  loop.allreduce_max_i32 = [](void* u, int32_t*, size_t) -> int {
+    ++static_cast<int*>(u)[1];
+    return 0;
+  };
+  loop.allgather = [](void* u, const void* mine, size_t bytes, void* all) -> int {
+    ++static_cast<int*>(u)[2];
+    std::memcpy(all, mine, bytes);
+    return 0;
+  };
+  cs_mesh_desc ld;
+  std::memset(&ld, 0, sizeof ld);
+  ld.tiles_x = ld.tiles_y = 1;
+  ld.halo_cells = 1;
+  ld.n_ranks = 1;
+  ld.host_transport = &loop;
+  cs_mesh* solo = cs_mesh_create(&grid, &ld);
+  CHECK(solo && cs_mesh_local_tiles(solo) == 1 && calls[1] == 1);  // (the layout checksum went through the all-reduce)
+  cs_engine* ref = cs_create(&grid, nullptr);
+  const uint32_t lp_s = cs_mesh_register_zanlungo(solo, &z), up_s = cs_mesh_register_hlp(solo, &up);
+  CHECK(lp_s == cs_register_zanlungo(ref, &z) && up_s == cs_register_hlp(ref, &up));
+  CHECK(cs_mesh_add_agents(solo, a_xy.data(), a_xy.size() / 2, up_s, lp_s, 2.0, nullptr) == 0);
+  CHECK(cs_add_agents(ref, a_xy.data(), a_xy.size() / 2, up_s, lp_s, 2.0, nullptr) == 0);
+  sd.lp = lp_s;
+  sd.hlp = cs_mesh_register_hlp(solo, &north);
+  CHECK(sd.hlp == cs_register_hlp(ref, &north));
+  CHECK(cs_mesh_add_source_sink(solo, &sd) == cs_add_source_sink(ref, &sd));
+  for (int k = 0; k < 80; ++k) CHECK(cs_step(ref, 0.05, nullptr) == 0 && cs_mesh_step(solo, 0.05, nullptr) == 0);
+  CHECK(cs_mesh_recut(solo) == 0);
+  const size_t n_solo = cs_agent_count(ref);
+  CHECK(cs_mesh_agent_count(solo) == n_solo && n_solo > a_xy.size() / 2);
+  std::vector<cs_agent_view> va(n_solo), vb(n_solo);
+  CHECK(cs_read_agents(ref, va.data(), n_solo) == n_solo && cs_mesh_read_agents(solo, vb.data(), n_solo) == n_solo);
+  CHECK(std::memcmp(va.data(), vb.data(), n_solo * sizeof(cs_agent_view)) == 0);
+  CHECK(cs_query_radius_batch(ref, 2, q, rad, 256, ids_a, cnt_a, nullptr, nullptr) == 0);
+  CHECK(cs_mesh_query_radius_batch(solo, 2, q, rad, 256, ids_b, cnt_b) == 0);
+  CHECK(cnt_a[0] == cnt_b[0] && std::memcmp(ids_a, ids_b, cnt_a[0] * sizeof(uint64_t)) == 0);
+  CHECK(calls[0] == 80 && calls[1] > 80 && calls[2] > 4);  // every step exchanged and OR-ed its spawn flags through the host
+  cs_mesh_destroy(solo);
+  cs_destroy(ref);
   std::printf("mesh api: passed (%zu agents)\n", n);
   return 0;
 }

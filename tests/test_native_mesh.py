@@ -253,5 +253,5 @@ def test_two_ranks_over_a_host_transport(tmp_path, kind, layout, port):
     assert len(a) > 50 and a.tobytes() == both.tobytes()
     assert sum(counts) == len(a) and min(counts) > 0
     probes = [(side * 0.5, side * 0.5), (side * 0.25, side * 0.6), (side * 0.75, side * 0.4)]
-    assert near == single.get_neighbours_in_radius_batch([6.0, 9.0, 4.0], probes)
-    assert knn == single.get_nearest_neighbours_batch(5, probes)
+    assert near == single.query_radius_batch([6.0, 9.0, 4.0], probes)
+    assert knn == single.query_knn_batch(5, probes)

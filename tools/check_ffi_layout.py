@@ -43,21 +43,24 @@ def strip_c_comments(text):
 
 
 def canon_c_type(t):
-    """'const double*' -> '*const f64'; 'cs_engine*' -> '*mut cs_engine'; 'const cs_x**' -> '*mut *const cs_x'."""
+    """'const double*' -> '*const f64'; 'cs_engine*' -> '*mut cs_engine'; 'const cs_x**' -> '*mut *const cs_x';
+    'const void* const*' -> '*const *const c_void'; 'void* const*' -> '*const *mut c_void' (a `const` qualifies what
+    stands to its left, or the base type when it comes first)."""
     t = t.strip()
-    stars = t.count("*")
-    base = t.replace("*", " ").split()
-    const = "const" in base
-    base = [w for w in base if w not in ("const", "struct")]
+    parts = [p.split() for p in t.split("*")]  # parts[0] = base type words, parts[k] = qualifiers after the k-th star
+    stars = len(parts) - 1
+    base = [w for w in parts[0] if w not in ("const", "struct")]
     assert len(base) == 1, t
     name = C_SCALARS.get(base[0], base[0])
     if stars == 0:
         return name
     if name == "void":
         name = "c_void"
-    out = ("*const " if const else "*mut ") + name
-    for _ in range(stars - 1):
-        out = "*mut " + out
+    # pointee constness per level: level 1 points at the base, level k at the (k-1)-th pointer
+    pointee_const = ["const" in parts[0]] + ["const" in parts[k] for k in range(1, stars)]
+    out = name
+    for k in range(stars):
+        out = ("*const " if pointee_const[k] else "*mut ") + out
     return out
 
 
