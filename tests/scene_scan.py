@@ -4,7 +4,7 @@
 arrays, oracle_fast_steps); prints how many steps each parameter set lasts before an agent goes
 non-finite or leaves the grid (what `Simulation::step` answers with Err("Index out of bounds")).
 
-    python tools/scene_scan.py [agents] [speed]
+    python tests/scene_scan.py [agents] [speed]
 
 Result: no.  The failure is geometric, not a gain instability: the larger id of a
 pair never yields (weight 0, zanlungo.rs:173-198), weak forces let walkers pass through each other
