@@ -579,7 +579,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
             out["creep_scene"] = creep_leg
             # the same crowd with forces that do not underflow: the figure to quote when the force path must count
             out["value_full_force"] = creep_leg["value"]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would wait for it)
             wl = args.workload if uniform_kind else "creep"
             out["cpu_baseline"] = cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)
             if uniform_kind:
