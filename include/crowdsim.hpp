@@ -365,9 +365,9 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
 // The same `Simulation`, cut into tiles_x x tiles_y spatial tiles: one tile engine per tile behind
 // the C ABI's mesh handle (cs_mesh_*: layout, halo exchange, spawn flags, route misses, re-cuts, merged queries all
 // in the library).  With `rccl_unique_id` (CS_RCCL_UNIQUE_ID_BYTES from cs_rccl_unique_id on one rank) the
-// distributed form: one tile per rank and GPU, `agents` then holds this rank's share; with a `host_transport`
-// (three functions over MPI, sockets, ...: cs_mesh_host_transport) instead of or beside it, `agents`, re-cuts and the
-// queries cover the whole crowd on every rank.  Results equal Simulation's bit for bit while nobody touches the
+// distributed form: one tile per rank and GPU; a `host_transport` (three functions over MPI, sockets, ...:
+// cs_mesh_host_transport) can stand in for RCCL or beside it.  In the distributed forms every call is collective and
+// `agents`, re-cuts and the queries cover the whole crowd on every rank.  Results equal Simulation's bit for bit while nobody touches the
 // domain's edges.
 class TiledSimulation {
  public:

@@ -475,6 +475,9 @@ int cs_halo_exchange_rccl(cs_engine*, int32_t axis);
 /* max over the ranks, element by element, in place (the OR of the spawn flags of
  * cs_spawn_probe_dev), on the engine's stream */
 int cs_allreduce_max_i32_rccl(cs_engine*, int* values_dev, size_t n);
+/* every rank's `bytes` bytes to every rank, in rank order (device buffers; recv_dev holds n_ranks * bytes), on the
+ * engine's stream */
+int cs_allgather_bytes_rccl(cs_engine*, const void* send_dev, void* recv_dev, size_t bytes);
 /* One multi-GPU step of a tile in one call: cs_halo_pack_all -> cs_halo_exchange_rccl(-1) ->
  * cs_halo_unpack_all -> (with source-sinks: cs_spawn_probe_dev -> cs_allreduce_max_i32_rccl ->
  * cs_spawn_commit_dev on flags the engine keeps) -> cs_step, all on the engine's stream.  For hosts
@@ -488,12 +491,13 @@ int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
  * for bit on scenes that stay clear of the domain's edges (a tile's grid edges are strict).
  *   rccl_unique_id null   every tile in this process on ONE device (exchanges are device copies on a shared stream)
  *   rccl_unique_id given  one tile per rank (n_ranks = tiles_x * tiles_y, also 1 x 1 with one rank), rank = tile index = tx * tiles_y + ty, halo records over RCCL from the
- *                  engine itself; cs_mesh_step and cs_mesh_remove_agent are then collective; re-cuts, merged
- *                  spatial queries and the route-cache misses of multi-leg sinks need a host_transport beside it
- *                  (or stay with the host: cs_tile_* / cs_query_*_batch / cs_route_misses per tile)
- *   host_transport given  the same one-tile-per-rank form over a transport of the host's (see above); with it
- *                  cs_mesh_recut, cs_mesh_query_*_batch, cs_mesh_agent_count / cs_mesh_read_agents (the whole crowd
- *                  on every rank) and multi-leg route followers work across ranks (all collective)
+ *                  engine itself (ncclSend / ncclRecv for the halos, ncclAllReduce for the spawn flags,
+ *                  ncclAllGather for what needs every rank's answer)
+ *   host_transport given  the same one-tile-per-rank form over a transport of the host's (see above), instead of
+ *                  RCCL or beside it (then it carries the gathers)
+ * In both distributed forms every cs_mesh_* call is collective (every rank makes it, in the same order), and
+ * cs_mesh_recut, cs_mesh_query_*_batch, cs_mesh_agent_count / cs_mesh_read_agents (the whole crowd on every
+ * rank), cs_mesh_remove_agent and multi-leg route followers work across ranks.
  *                  Every rank passes the same grid and the same descriptor but for `rank` and the device: layout
  *                  and halo capacities are computed from them on each rank and are not exchanged.
  * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics). */
@@ -553,7 +557,7 @@ void cs_mesh_event_recording(cs_mesh*, int on);
 size_t cs_mesh_drain_events(cs_mesh*, cs_event* out, size_t cap);
 int cs_mesh_step(cs_mesh*, double dt_seconds, cs_step_report* report);            /* lib.rs:195-383 */
 int cs_mesh_synchronize(cs_mesh*);
-size_t cs_mesh_agent_count(cs_mesh*);      /* the local tiles' agents; over all ranks with a host transport (collective) */
+size_t cs_mesh_agent_count(cs_mesh*);      /* the whole crowd (distributed forms: collective) */
 size_t cs_mesh_read_agents(cs_mesh*, cs_agent_view* out, size_t cap);             /* ascending id; SIZE_MAX on error */
 int cs_mesh_tile_counts(cs_mesh*, uint64_t* out_per_local_tile);
 int cs_mesh_recut(cs_mesh*);

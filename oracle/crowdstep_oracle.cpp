@@ -1132,6 +1132,10 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int*, size_t) {
   e->error = "oracle has no tiles";
   return 3;
 }
+int cs_allgather_bytes_rccl(cs_engine* e, const void*, void*, size_t) {
+  e->error = "oracle has no tiles";
+  return 3;
+}
 int cs_tile_step_rccl(cs_engine* e, double, cs_step_report*) {
   e->error = "oracle has no tiles";
   return 3;

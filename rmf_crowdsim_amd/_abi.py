@@ -207,6 +207,7 @@ SYMBOLS = {
     "cs_halo_set_peers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "cs_halo_exchange_rccl": (C.c_int, [C.c_void_p, C.c_int32]),
     "cs_allreduce_max_i32_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cs_allgather_bytes_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "cs_tile_step_rccl": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(StepReport)]),
     "cs_mesh_create": (C.c_void_p, [C.POINTER(GridDesc), C.POINTER(MeshDesc)]),
     "cs_mesh_destroy": (None, [C.c_void_p]),

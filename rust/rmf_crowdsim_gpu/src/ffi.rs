@@ -308,6 +308,7 @@ extern "C" {
     pub fn cs_halo_set_peers(e: *mut cs_engine, peers8: *const i32) -> c_int;
     pub fn cs_halo_exchange_rccl(e: *mut cs_engine, axis: i32) -> c_int;
     pub fn cs_allreduce_max_i32_rccl(e: *mut cs_engine, values_dev: *mut c_int, n: usize) -> c_int;
+    pub fn cs_allgather_bytes_rccl(e: *mut cs_engine, send_dev: *const c_void, recv_dev: *mut c_void, bytes: usize) -> c_int;
     pub fn cs_tile_step_rccl(e: *mut cs_engine, dt_seconds: f64, report: *mut cs_step_report) -> c_int;
 
     pub fn cs_mesh_create(grid: *const cs_grid_desc, desc: *const cs_mesh_desc) -> *mut cs_mesh;

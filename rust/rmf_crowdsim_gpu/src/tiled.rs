@@ -25,13 +25,12 @@ pub enum Placement {
     /// around by the host (MPI, a file, a socket)
     Distributed { device: i32, rank: i32, n_ranks: i32, unique_id: [u8; ffi::CS_RCCL_UNIQUE_ID_BYTES] },
     /// one tile per rank over a transport the host brings (`ffi::cs_mesh_host_transport`: three `extern "C"`
-    /// functions over MPI, sockets, ...; host memory throughout), instead of RCCL; with it re-cuts, merged queries,
-    /// `agents` of the whole crowd and multi-leg route followers work across ranks.  The struct must outlive the mesh.
+    /// functions over MPI, sockets, ...; host memory throughout), instead of RCCL.  The struct must outlive the mesh.
     HostTransport { device: i32, rank: i32, n_ranks: i32, transport: &'static ffi::cs_mesh_host_transport },
 }
 
 pub struct TiledSimulation {
-    /// lib.rs:71.  Distributed: the agents of this rank's tile.
+    /// lib.rs:71.  Distributed: the whole crowd on every rank (the refresh is collective).
     pub agents: HashMap<AgentId, Agent>,
     mesh: *mut ffi::cs_mesh,
     hlp_handles: HashMap<usize, u32>,

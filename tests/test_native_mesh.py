@@ -157,7 +157,7 @@ def test_recut_and_queries_on_a_native_mesh():
 def test_distributed_form_with_one_rank():
     """The distributed form of the mesh (a tile per rank, halo records over RCCL from the engine, the whole step one
     call: cs_tile_step_rccl) with the one rank a one-GPU box allows: a 1 x 1 mesh on a communicator of one.  Device
-    path, host path (a report), source-sinks, a removal: the single engine's bits."""
+    path, host path (a report), source-sinks, a removal, a re-cut, merged queries: the single engine's bits."""
     grid = dict(width=60.0, height=60.0, cell_size=2.0, offset=(0.0, 0.0))
     single = Simulation(LocationHash2D(**grid))
     uid = single.rccl_unique_id()
@@ -176,8 +176,18 @@ def test_distributed_form_with_one_rank():
         single.step(0.05, report=False)
         mesh.step(0.05, report=False)
     assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
-    with pytest.raises(Exception, match="re-cut by its host"):
-        mesh.recut()
+    # what needs every rank's answer (agents of the whole crowd, re-cut, merged queries) goes through ncclAllGather /
+    # ncclAllReduce from the engine when the host brought no transport of its own: here on the communicator of one
+    mesh.recut()
+    for _ in range(5):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes() and len(mesh) == len(single)
+    probes = [(30.0, 30.0), (20.0, 41.0)]
+    assert mesh.get_neighbours_in_radius_batch([6.0, 9.0], probes) == single.query_radius_batch([6.0, 9.0], probes)
+    assert mesh.get_nearest_neighbours_batch(4, probes) == single.query_knn_batch(4, probes)
+    with pytest.raises(Exception, match="unknown agent id"):
+        mesh.remove_agents(10 ** 9)
 
 
 # ---- the distributed form over a transport the HOST brings (cs_mesh_host_transport) ----------------------

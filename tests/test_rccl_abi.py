@@ -42,6 +42,9 @@ def test_hand_written_rccl_declarations_match_the_header(tmp_path):
         static_assert(std::is_same<decltype(&ncclAllReduce), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t,
                                                                              ncclRedOp_t, ncclComm_t, hipStream_t)>::value,
                       "ncclAllReduce");
+        static_assert(std::is_same<decltype(&ncclAllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t,
+                                                                             ncclComm_t, hipStream_t)>::value,
+                      "ncclAllGather");
         static_assert(std::is_same<decltype(&ncclGroupStart), ncclResult_t (*)()>::value &&
                       std::is_same<decltype(&ncclGroupEnd), ncclResult_t (*)()>::value, "group calls");
         static_assert(std::is_same<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>::value, "error string");
@@ -59,5 +62,6 @@ def test_the_engine_declares_what_the_check_restates():
                    "typedef int (*SendFn)(const void*, size_t, int, int, Comm, hipStream_t);",
                    "typedef int (*RecvFn)(void*, size_t, int, int, Comm, hipStream_t);",
                    "typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);",
+                   "typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);",
                    "constexpr int kUint8 = 1, kInt32 = 2, kMax = 2;"):
         assert needle in text, needle
