@@ -462,7 +462,7 @@ class NativeTileMesh:
     the same interface as LocalTileMesh, whose Python orchestration it replaces; with `rccl_unique_id` (bytes from
     Simulation.rccl_unique_id() on one rank, passed around by the host) and / or `host_transport` (a
     TorchHostTransport, or anything with a `.struct` of type _abi.MeshHostTransport) the distributed form: this
-    rank's tile only; with a host transport read_agents, len(), re-cuts and queries cover the whole crowd (collective)."""
+    rank's tile only; every call is collective then, and read_agents, len(), re-cuts and queries cover the whole crowd."""
 
     def __init__(self, spatial_index, tiles, halo_cells, device=0, density_per_cell=16.0, flags=0, weights=None,
                  capacity_hint=0, library=None, rank=0, n_ranks=1, rccl_unique_id=None, host_transport=None):
