@@ -1059,19 +1059,6 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int* values_dev, size_t n) {
                       "ncclAllReduce") ? 0 : 8;
 }
 
-// every rank's `bytes` bytes to every rank, in rank order (device buffers; recv holds n_ranks * bytes), on the
-// engine's stream: what a mesh's re-cuts, merged queries and route-cache misses need
-int cs_allgather_bytes_rccl(cs_engine* e, const void* send_dev, void* recv_dev, size_t bytes) {
-  hipSetDevice(e->device);
-  rccl_api::Api& a = rccl_api::api();
-  if (!a.handle || !e->rccl_comm) {
-    e->error = a.handle ? "no RCCL communicator: call cs_rccl_comm_init or cs_rccl_comm_adopt first" : a.why;
-    return 8;
-  }
-  if (bytes == 0) return 0;
-  return rccl_api::ok(e, a.all_gather(send_dev, recv_dev, bytes, rccl_api::kUint8, e->rccl_comm, e->stream), "ncclAllGather") ? 0 : 8;
-}
-
 // The whole multi-GPU step of a tile in ONE call, on the engine's stream, nothing waiting for the
 // host: halo pack -> RCCL exchange -> unpack -> (source-sinks: device-side probe, all-reduce of the
 // flags, commit) -> cs_step.  For hosts without listeners, host planners or multi-leg route sinks
