@@ -21,6 +21,21 @@ class Env:
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "mesh"
+if os.environ.get("CS_FUZZ_NATIVE") == "1":
+    # the same randomized mesh tests with the C ABI's mesh (cs_mesh_*, tiles.NativeTileMesh) standing in for the
+    # Python orchestration (tiles.LocalTileMesh)
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+
+    class NativeAsLocal(NativeTileMesh):
+        def __init__(self, index, tiles, halo_cells=1, phases=1, **kw):
+            if phases != 1:
+                raise pytest.skip.Exception("the native mesh has the one-phase schedule only")
+            super().__init__(index, tiles, halo_cells, **kw)
+
+        @property
+        def engines(self):  # (the tests sum reports and counts over a mesh's engines: the mesh's own are those sums)
+            return [self]
+    T.LocalTileMesh = NativeAsLocal
 if which == "bigmesh":  # crowds large enough for the LDS-tiled kernel on every tile: border / interior launches, fused pack
     import math
     import numpy as np
