@@ -203,6 +203,59 @@ def test_overlapping_pairs_collide_now_whatever_their_relative_velocity(vx, flag
     assert out[1][0] == (0 if vx == 0.0 else 2)
 
 
+@pytest.mark.parametrize("flags", [2, 1], ids=["tiled", "gather"])
+def test_an_agent_thrown_by_the_clamp_takes_its_neighbours_with_it(flags):
+    """zanlungo.rs:165-167 clamps the force of an overlapping pair at 1e15, which throws the yielding agent at
+    ~1e15 m/s; in the next step everybody who sees it has a time to collision of ~1e-15 s with it and is thrown in
+    turn (the reference's cascade).  With relative positions in fixed units (2^22 per metre) the quadratic's bh^2
+    would leave f32's range for such a pair and read as "no collision": pairs faster than 2^32 m/s are rescaled
+    (ttc_huge).  Steps with dt = 0 commit the velocities and leave everybody on the grid.  Twelve random clusters:
+    same NaN pattern, same thrown agents, velocities to 1e-5 of their length, as the f64 oracle."""
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        centre = np.array([50.0, 50.0]) + rng.uniform(-0.9, 0.9, 2)
+        ang, d = rng.uniform(0, 2 * np.pi), rng.uniform(0.03, 0.18)
+        pts = [centre, centre + d * np.array([np.cos(ang), np.sin(ang)])]          # the overlapping pair
+        pts += [centre + rng.uniform(0.6, 3.5) * np.array([np.cos(a), np.sin(a)]) for a in rng.uniform(0, 2 * np.pi, 8)]
+        vels = [tuple(rng.uniform(-1, 1, 2)) for _ in pts]
+        out = []
+        for cls in (Simulation, OracleSimulation):
+            kw = dict(flags=flags) if cls is Simulation else {}
+            sim = cls(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)), **kw)
+            lp = Zanlungo(0.02, 1.0, 0.0, 0.4, 2.0, 0.2)
+            for p, v in zip(pts, vels):
+                sim.add_agents([tuple(p)], StubHighLevelPlan(v), lp, 5.0)
+            trace = []
+            for _ in range(4):  # 1: velocities set; 2: the pair collides, one is thrown; 3, 4: the cascade
+                sim.step(0.0)
+                a = sim.read_agents()
+                trace.append((a["vx"].copy(), a["vy"].copy()))
+            out.append(trace)
+        for k, ((ex, ey), (ox, oy)) in enumerate(zip(*out)):
+            assert (np.isnan(ex) == np.isnan(ox)).all() and (np.isnan(ey) == np.isnan(oy)).all(), (case, k)
+            ok = ~np.isnan(ox)
+            err = np.hypot(ex[ok] - ox[ok], ey[ok] - oy[ok])  # (against the vector's length: a sum of 1e15-sized terms)
+            assert (err <= 1e-5 * np.hypot(ox[ok], oy[ok]) + 1e-6).all(), (case, k, float(err.max()))
+    # ... and the pair itself, without the dice: a walker at 1e15 m/s (its planner says so) three metres from a
+    # standing agent in its path: t_i = 2.8e-15 s, the force clamps, and the engine must see it as the oracle does
+    out = []
+    for cls in (Simulation, OracleSimulation):
+        kw = dict(flags=flags) if cls is Simulation else {}
+        sim = cls(LocationHash2D(100.0, 100.0, 2.0, (0.0, 0.0)), **kw)
+        lp = Zanlungo(0.02, 1.0, 0.0, 0.4, 2.0, 0.2)
+        sim.add_agents([(50.0, 50.0)], StubHighLevelPlan((1e15, 0.0)), lp, 5.0)
+        sim.add_agents([(53.0, 50.05)], StubHighLevelPlan((0.0, 0.0)), lp, 5.0)
+        sim.add_agents([(51.0, 53.0)], StubHighLevelPlan((0.0, 0.3)), lp, 5.0)
+        sim.step(0.0)
+        sim.step(0.0)
+        a = sim.read_agents()
+        out.append(np.stack([a["vx"], a["vy"]], axis=1))
+        assert sim.last_report["n_tti_zero"] == 0
+    e, o = out
+    assert np.isfinite(o).all() and abs(o[0, 1]) > 1e12  # the walker was pushed aside with the clamped force
+    assert (np.hypot(*(e - o).T) <= 1e-5 * np.hypot(*o.T) + 1e-6).all(), (e, o)
+
+
 # ---- config 1: the visualiser's scene ---------------------------------------------------
 def test_viz_scene_literal_1000_steps():
     """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),
