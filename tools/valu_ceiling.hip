@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(256) k_issue(float* out, int iters, float seed
         break;
       case K_LDS_WRITE16:
 #pragma unroll
-        // (2 bytes per lane, the step kernel's list rows; with the 16-byte stride of the reads above the 64 lanes
-        // would share 16 banks, a 4-way conflict: 7.6e10 /s where this form gives the conflict-free rate)
+        // (2 bytes per lane, the step kernel's list rows.  7.6e10 /s = 8 clocks per wave64 and CU at this stride AND at
+        // the 16-byte stride of the reads above: the rate of sub-dword LDS writes, not a bank conflict)
         for (int k = 0; k < UNROLL; ++k) asm volatile("ds_write_b16 %0, %1" : : "v"(addr >> 3), "v"(a[k]));
         asm volatile("s_waitcnt lgkmcnt(0)");
         break;
