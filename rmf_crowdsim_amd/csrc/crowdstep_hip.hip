@@ -187,6 +187,11 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   ok = ok && hipMalloc(&e->ctr, sizeof(Counters)) == hipSuccess;
   ok = ok && hipHostMalloc(&e->ctr_host, sizeof(Counters)) == hipSuccess;
   if (ok) hipMemset(e->ctr, 0, sizeof(Counters));
+  if (const char* v = getenv("CS_FIRST_AGENT_ID")) {  // test knob: ids near the 31-bit limit without 2^31 agents
+    e->next_id = std::min<uint64_t>((uint64_t)strtoull(v, nullptr, 10), CS_ID_LIMIT);
+    const uint32_t nid = (uint32_t)e->next_id;
+    if (ok) hipMemcpy(&e->ctr->next_id, &nid, sizeof nid, hipMemcpyHostToDevice);
+  }
   if (!ok || e->upload_sinks() != 0 ||
       e->reserve(cfg && cfg->capacity_hint ? cfg->capacity_hint : 1024) != 0) {
     return create_failed(e, "device allocation failed: " + e->error);

@@ -256,6 +256,36 @@ def test_an_agent_thrown_by_the_clamp_takes_its_neighbours_with_it(flags):
     assert (np.hypot(*(e - o).T) <= 1e-5 * np.hypot(*o.T) + 1e-6).all(), (e, o)
 
 
+@pytest.mark.parametrize("flags", [2, 1], ids=["tiled", "gather"])
+def test_ids_up_to_the_31_bit_limit(flags, monkeypatch):
+    """Device ids are below 2^31: the tiled kernel takes the right-of-way bit of a neighbour from the sign of
+    (own id - neighbour's id).  A crowd whose ids end one short of the limit (CS_FIRST_AGENT_ID, a test knob) moves
+    exactly like the same crowd with ids from 0 (only the ORDER of ids matters to the model), the ids come back as
+    they were handed out, and the agent that would need id 2^31 - 1 is refused with the documented error."""
+    n = 6000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=5, cell_size=2.0)
+    runs = []
+    for first in (0, 2 ** 31 - 1 - n):
+        if first:
+            monkeypatch.setenv("CS_FIRST_AGENT_ID", str(first))
+        else:
+            monkeypatch.delenv("CS_FIRST_AGENT_ID", raising=False)
+        sim = Simulation(LocationHash2D(**grid), flags=flags)
+        ids = scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, Zanlungo(*scenes.METRIC_ZANLUNGO), 2.0)
+        assert sorted(int(i) for i in ids) == list(range(first, first + n))
+        for _ in range(20):
+            sim.step(0.05, report=False)
+        a = sim.read_agents()
+        assert (a["id"] == np.arange(first, first + n)).all()
+        runs.append(a)
+        if first:
+            with pytest.raises(CrowdSimError, match="agent id space exhausted"):
+                sim.add_agents([(extent / 2, extent / 2)], StubHighLevelPlan((0.0, 0.0)), NoLocalPlan(), 1.0)
+    for field in ("x", "y", "vx", "vy", "next_waypoint"):
+        assert (runs[0][field] == runs[1][field]).all(), field
+    assert np.abs(runs[0]["vx"]).max() > 0.0 and not (runs[0]["vx"] == 0.0).all()  # forces acted
+
+
 # ---- config 1: the visualiser's scene ---------------------------------------------------
 def test_viz_scene_literal_1000_steps():
     """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),
