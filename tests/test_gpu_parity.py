@@ -261,11 +261,11 @@ def test_ids_up_to_the_31_bit_limit(flags, monkeypatch):
     """Device ids are below 2^31: the tiled kernel takes the right-of-way bit of a neighbour from the sign of
     (own id - neighbour's id).  A crowd whose ids end one short of the limit (CS_FIRST_AGENT_ID, a test knob) moves
     exactly like the same crowd with ids from 0 (only the ORDER of ids matters to the model), the ids come back as
-    they were handed out, and the agent that would need id 2^31 - 1 is refused with the documented error."""
+    they were handed out, and the agent that would need id 2^31 - 2 is refused with the documented error."""
     n = 6000
     pts, grid, extent, group = scenes.uniform_crowd(n, seed=5, cell_size=2.0)
     runs = []
-    for first in (0, 2 ** 31 - 1 - n):
+    for first in (0, 2 ** 31 - 2 - n):  # (the engine keeps the last id below the limit, 2^31 - 1, free)
         if first:
             monkeypatch.setenv("CS_FIRST_AGENT_ID", str(first))
         else:
