@@ -340,6 +340,7 @@ struct Zanlungo : LocalPlanner {
     return t == Real(0) && norm2(rel_pos) - agent_radius * agent_radius > Real(0) && norm2(rel_vel) < Real(1e-30);
   }
   mutable std::vector<uint64_t>* spurious_victims = nullptr;  // ids whose t_i came out 0 through such a pair
+  mutable uint64_t* degenerate_flips = nullptr;               // (oracle_degenerate_flips)
 
   // :76-91 — strict `<` from +inf, all neighbours regardless of id
   Real compute_tti(const Agent& me, const std::vector<Agent>& nearby) const {
@@ -409,6 +410,12 @@ struct Zanlungo : LocalPlanner {
         // other wants to stand still: steer orthogonally to the current displacement
         V2 q = me.position - other.position;
         perp = {-q.y, q.x};
+        // (certification of parity scenes: a neighbour straight ahead or behind makes this dot product zero in exact
+        // arithmetic, its computed sign is rounding noise, and a 32-bit reading of the same line may flip the other
+        // way: DESIGN.md section 5.  Counted while the term matters: finite t_i, the neighbour has right of way.)
+        if (degenerate_flips && std::isfinite((double)t_i) &&
+            std::fabs((double)dot(perp, me.velocity)) <= 1e-9 * (double)norm(perp) * (double)norm(me.velocity))
+          ++*degenerate_flips;
         if (dot(perp, me.velocity) < Real(0)) perp = -perp;
       } else {
         // other is going somewhere: steer orthogonally to its preferred direction
@@ -629,6 +636,7 @@ struct cs_engine {
   // reference's in-loop index update (lib.rs:299) could make it differ from the Jacobi result
   bool count_shell = false;
   std::vector<uint64_t> spurious_victims;  // (oracle_spurious_victims)
+  uint64_t degenerate_flips = 0;           // (oracle_degenerate_flips)
   uint64_t last_shell_crossings = 0;
 
   explicit cs_engine(const cs_grid_desc& g)
@@ -1274,6 +1282,13 @@ size_t oracle_spurious_victims(cs_engine* e, uint64_t* out, size_t cap) {
     if (auto* z = dynamic_cast<Zanlungo*>(lp.get())) z->spurious_victims = &e->spurious_victims;
   for (size_t k = 0; k < e->spurious_victims.size() && k < cap; ++k) out[k] = e->spurious_victims[k];
   return e->spurious_victims.size();
+}
+// force terms so far whose sideways direction hung on the sign of a dot product that is zero to rounding (a
+// neighbour straight ahead or behind: Zanlungo::compute_agent_force); counted from the first call on
+uint64_t oracle_degenerate_flips(cs_engine* e) {
+  for (auto& lp : e->lps)
+    if (auto* z = dynamic_cast<Zanlungo*>(lp.get())) z->degenerate_flips = &e->degenerate_flips;
+  return e->degenerate_flips;
 }
 uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; }
 

@@ -40,6 +40,8 @@ def load_oracle(kind="f64"):
     lib.oracle_fast_steps.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
                                       [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int,
                                                                  ctypes.POINTER(ctypes.c_uint8)])
+    lib.oracle_degenerate_flips.restype = ctypes.c_uint64
+    lib.oracle_degenerate_flips.argtypes = [ctypes.c_void_p]
     lib.oracle_spurious_victims.restype = ctypes.c_size_t
     lib.oracle_spurious_victims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
     dp = ctypes.POINTER(ctypes.c_double)
@@ -67,6 +69,12 @@ class OracleSimulation(Simulation):
         buf = np.zeros(max(n, 1), dtype=np.uint64)
         self._lib.oracle_spurious_victims(self._engine, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n)
         return set(int(i) for i in buf[:n])
+
+    def degenerate_flips(self):
+        """Force terms so far whose sideways direction hung on the sign of a dot product that is zero to rounding (a
+        neighbour straight ahead or behind the agent: walkers in file), DESIGN.md section 5.  Counted from the first
+        call on: call it once before stepping.  Planners registered later are picked up by the next call."""
+        return int(self._lib.oracle_degenerate_flips(self._engine))
 
     def count_shell_crossings(self, on=True):
         """from now on count, per step, the ordered neighbour pairs whose
