@@ -286,6 +286,29 @@ def test_ids_up_to_the_31_bit_limit(flags, monkeypatch):
     assert np.abs(runs[0]["vx"]).max() > 0.0 and not (runs[0]["vx"] == 0.0).all()  # forces acted
 
 
+@pytest.mark.parametrize("flags", [2, 1], ids=["tiled", "gather"])
+def test_a_dead_model_does_not_keep_the_gpu_busy(flags):
+    """Steps without a report return before the device has finished: a crowd whose model blows up in step 2
+    (40 agents per cell walking into each other at 0.3 m/s: t_i = 0, the 1e15 clamp, everybody NaN in cell 0 within a
+    few steps) used to be stepped on for as long as nobody looked, at 35 s per step (one cell of 50,000 agents is
+    quadratic work: found by tools/fuzz_more.py kernels, seed 1010).  The step kernels now leave at once when an agent
+    has left the grid: that step has failed, and the engine is poisoned at the next synchronisation."""
+    import time
+    rng = np.random.default_rng(99000 + 1010)
+    pts, grid, extent, group = scenes.uniform_crowd(50652, seed=1010, cell_size=4.0)
+    part = rng.integers(0, 4, size=len(pts))
+    sim = Simulation(LocationHash2D(**grid), flags=flags)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    for k in range(4):
+        sim.add_agents(pts[part == k], StubHighLevelPlan((0.3 * (1 if k % 2 else -1), 0.09 * (k - 1.5))), lp, 3.0)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        sim.step(0.05, report=False)
+    with pytest.raises(CrowdSimError, match="Index out of bounds"):
+        sim.read_agents()
+    assert time.perf_counter() - t0 < 20.0
+
+
 # ---- config 1: the visualiser's scene ---------------------------------------------------
 def test_viz_scene_literal_1000_steps():
     """rmf_crowdsim_viz/src/main.rs:64-94 verbatim: 3 agents, Zanlungo(1,1,0,40,2,20),

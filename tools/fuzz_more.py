@@ -101,7 +101,7 @@ if which == "kernels":  # the LDS-tiled kernel against the gather kernel, bit fo
                 v = (speed * (1 if k % 2 else -1), speed * 0.3 * (k - 1.5))
                 sim.add_agents(pts[part == k], StubHighLevelPlan(v), lp, eyes)
             try:
-                for _ in range(6):
+                for _ in range(int(os.environ.get("CS_FUZZ_STEPS", "6"))):
                     sim.step(0.05, report=False)
                 outs.append(sim.read_agents().tobytes())
             except Exception as err:
