@@ -232,17 +232,18 @@ def _rank_host_transport(rank, world, port, out_path, kind, layout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,layout,port", [("sinks", (2, 1), 29741), ("legs", (1, 2), 29742)])
+@pytest.mark.parametrize("kind,layout,port", [("sinks", (2, 1), 29741), ("legs", (1, 2), 29742), ("sinks", (2, 2), 29743)])
 def test_two_ranks_over_a_host_transport(tmp_path, kind, layout, port):
-    """The distributed cs_mesh over a transport of the host's (here torch.distributed / gloo: two ranks sharing the
-    one GPU): same bits as one engine after 400 steps with a removed sink, a removed agent and a re-cut on the way;
+    """The distributed cs_mesh over a transport of the host's (here torch.distributed / gloo: two or four ranks sharing
+    the one GPU): same bits as one engine after 400 steps with a removed sink, a removed agent and a re-cut on the way;
     read_agents and the batch queries answer for the whole crowd on every rank."""
     import pickle
     import torch.multiprocessing as mp
     from test_gpu_tiles import _TWO_RANK_GRID, _two_rank_scene
     ctx = mp.get_context("spawn")
     out = str(tmp_path / "host_transport.pkl")
-    procs = [ctx.Process(target=_rank_host_transport, args=(r, 2, port, out, kind, layout)) for r in range(2)]
+    world = layout[0] * layout[1]  # (2 x 2: four ranks, diagonal neighbours exchange corner records)
+    procs = [ctx.Process(target=_rank_host_transport, args=(r, world, port, out, kind, layout)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
