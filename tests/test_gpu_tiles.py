@@ -168,7 +168,7 @@ def test_hotspot_crowd_with_weighted_cuts_matches_single_engine():
 
 
 # ---- one rank per tile, two processes sharing the one GPU of the test box ----------------
-def _rank_main(rank, world, port, out_path):
+def _rank_main(rank, world, port, out_path, layout=(2, 1)):
     import os
     import pickle
     import torch
@@ -181,7 +181,7 @@ def _rank_main(rank, world, port, out_path):
         n = 20000
         pts, grid, extent, group = scenes.uniform_crowd(n, seed=13, cell_size=2.0, margin=20.0)
         lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
-        tiles = DistributedTiles(LocationHash2D(**grid), (2, 1), halo_cells=1, device=0)
+        tiles = DistributedTiles(LocationHash2D(**grid), layout, halo_cells=1, device=0)
         _populate(tiles, pts, group, [(1.30, 0.4), (1.28, 0.4)], lp, 2.0)
         for _ in range(40):
             tiles.step(0.05)
@@ -197,12 +197,16 @@ def _rank_main(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_distributed_tiles_two_ranks(tmp_path):
+@pytest.mark.parametrize("layout,port", [((2, 1), 29721), ((2, 2), 29722)])
+def test_distributed_tiles_two_ranks(tmp_path, layout, port):
+    """(2 x 2: four ranks sharing the GPU; diagonal neighbours exchange corner records, as five of a 4 x 2 mesh's
+    eight tiles' neighbours do on an 8-GPU node.)"""
     import pickle
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = str(tmp_path / "ranks.pkl")
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29721, out)) for r in range(2)]
+    world = layout[0] * layout[1]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out, layout)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
