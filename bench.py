@@ -99,7 +99,9 @@ def cpu_baseline(agents, cell, eyesight, speed, workload="walk", budget_s=15.0):
     return {
         "value": n * steps / el, "unit": "agent-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n} agents x {steps} steps of the same scene (density, planner, eyesight, dt), "
-                  f"oracle/crowdstep_oracle.cpp f64 single thread, {el:.1f} s",
+                  f"oracle/crowdstep_oracle.cpp f64 single thread, {el:.1f} s; sampled at {n} agents because the port "
+                  f"takes ~3 us per agent-step (1M agents: 3 s per step, and minutes to fill its hash maps) and its "
+                  f"rate does not improve with the population (hash-map bound: the larger crowd only misses cache more)",
     }
 
 
@@ -170,6 +172,14 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="--gpus > 1: CS_CFG_TILE_OVERLAP (the next step's halo exchange runs behind the border "
                          "windows' launch on a second stream while the interior windows are stepped)")
+    ap.add_argument("--mesh", choices=["native", "python"], default="native",
+                    help="--gpus > 1: what steps the tiles.  native (default): the C ABI's own mesh, cs_mesh_* "
+                         "(csrc/cs_mesh.hip.inc; what a Rust or C++ host binds: one cs_mesh_step per step, halo records "
+                         "over RCCL from the engine; under CS_BENCH_BACKEND=gloo over a host transport).  python: "
+                         "tiles.DistributedTiles, the Python orchestration of the same tile engines, for comparison")
+    ap.add_argument("--verify", action="store_true",
+                    help="--gpus > 1 with --mesh native: after the timed region rank 0 steps a single engine through the "
+                         "same scene and the whole crowd of the mesh must equal it bit for bit (exit code 6 otherwise)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation bits (profiling only)")
     ap.add_argument("--planner", choices=["stub", "route"], default="stub",
                     help="stream workload: constant-velocity stub planners (the reference tests' kind) or "
@@ -197,21 +207,33 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     n_dev = torch.cuda.device_count()
-    if backend == "nccl" and world > n_dev:
+    if backend == "nccl" and world > n_dev and not os.environ.get("CS_BENCH_SHARE_DEVICE"):  # (the variable: a test of the
+        # loud-failure path: RCCL itself then refuses the second rank of a device)
         raise SystemExit(f"bench: {world} ranks but {n_dev} visible GPU(s): RCCL needs one device per rank "
                          f"(CS_BENCH_BACKEND=gloo lets ranks share a device, for functional tests only)")
-    device = local_rank % n_dev if backend != "nccl" else local_rank
+    device = local_rank % n_dev if (backend != "nccl" or os.environ.get("CS_BENCH_SHARE_DEVICE")) else local_rank
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            else:
+                dist.init_process_group(backend)
+        except Exception as err:  # noqa: BLE001
+            print(f"bench: rank {rank} FAILED in phase 'process group init ({backend})': {err}", file=sys.stderr, flush=True)
+            os._exit(5)
     if args.scaling is None:
         # the metric is quoted at 1M agents IN ALL (BASELINE.json configs[2]: 4 x 2 tiles of one 1M crowd)
         args.scaling = "strong"
     ctx = dict(torch=torch, dist=dist, rank=rank, world=world, device=device, backend=backend)
+
+    def fail(phase, err):
+        """A rank that cannot go on says in which phase and leaves at once with a non-zero code (no unwinding through
+        collectives its peers are not in; the launcher ends the other ranks)."""
+        print(f"bench: rank {rank} FAILED in phase '{phase}': {err}", file=sys.stderr, flush=True)
+        os._exit(5)
+    ctx["fail"] = fail
 
     # N > 1: the first run of this code over RCCL with real peers may be the driver's.  A rank that sits in one
     # phase for --watchdog seconds says where and leaves; if the headline leg is already measured (the stall is in
@@ -226,7 +248,8 @@ def main():
                   flush=True)
             if rank == 0 and progress["line"] is not None:
                 print(progress["line"], flush=True)
-            os._exit(0 if (progress["line"] is not None or progress.get("printed")) else 3)
+            # 3: nothing measured; 4: the headline line stands (printed above or before), an extra leg or the shutdown hung
+            os._exit(4 if (progress["line"] is not None or progress.get("printed")) else 3)
 
         def arm(phase):
             nonlocal watchdog
@@ -240,6 +263,7 @@ def main():
     else:
         def arm(phase):
             progress["phase"] = phase
+    ctx["arm"] = arm
 
     main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
     other_leg = None
@@ -262,9 +286,13 @@ def main():
         print(json.dumps(out), flush=True)
     progress["line"], progress["printed"] = None, True
     arm("shutdown")
+    verdicts = [main_leg["tile_report"].get("verify")] + ([other_leg.get("verify")] if other_leg else [])
+    bad_verify = any(isinstance(v, dict) and not v.get("mesh_equals_single_engine", True) for v in verdicts)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if bad_verify:
+        raise SystemExit(6)
 
 
 def launch_ranks_if_needed(args):
@@ -284,6 +312,80 @@ def launch_ranks_if_needed(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+class TileCounts:
+    """Agents per tile of a set of positions under the cuts a mesh of this shape gets (the library cuts the same way:
+    tiles.TileLayout mirrors cs_mesh_create's mesh_even_edges / mesh_weighted_edges; tests/test_native_mesh.py)."""
+
+    def __init__(self, spatial_index, tiling, weights, halo):
+        from rmf_crowdsim_amd.tiles import TileLayout
+        self.index = spatial_index
+        self.layout = TileLayout(spatial_index, *tiling, weights=weights, min_cells=2 * int(halo))
+
+    def of(self, pts):
+        return self.layout.tile_counts(pts, self.index)
+
+
+def make_mesh(args, ctx, spatial_index, tiling, halo, density, capacity, flags, weights):
+    """N > 1: this rank's tile of the crowd.  Returns (what is stepped, the tile's engine for profiling, report)."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    rank, world, device, backend = ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
+    if args.mesh == "python":
+        from rmf_crowdsim_amd.tiles import DistributedTiles
+        stepper = DistributedTiles(spatial_index, tiling, halo, device, density_per_cell=density, capacity_hint=capacity,
+                                   flags=flags, weights=weights)
+        return stepper, stepper.sim, {"mesh": "python", "transport": stepper.transport, "entry_point": "tiles.DistributedTiles.step"}
+    import ctypes as C
+    from rmf_crowdsim_amd import _abi, _native
+    from rmf_crowdsim_amd.tiles import NativeTileMesh, TorchHostTransport
+    if backend == "nccl":
+        # rank 0 makes the communicator's id, the launcher's process group hands it round; from then on every byte of
+        # the step travels over RCCL from the engine (what a Rust host does with MPI or a file in torch's place)
+        box = [None]
+        if rank == 0:
+            raw = (C.c_uint8 * _abi.CS_RCCL_UNIQUE_ID_BYTES)()
+            if _native.load().cs_rccl_unique_id(raw) != 0:
+                box = [RuntimeError("cs_rccl_unique_id failed: librccl could not be bound")]
+            else:
+                box = [bytes(raw)]
+        dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], Exception):
+            raise box[0]
+        stepper = NativeTileMesh(spatial_index, tiling, halo, device=device, density_per_cell=density, flags=flags,
+                                 weights=weights, capacity_hint=capacity, rank=rank, n_ranks=world, rccl_unique_id=box[0])
+        transport = "rccl (ncclSend / ncclRecv issued by the engine on its stream)"
+    else:
+        # functional double (ranks may share a GPU): the same cs_mesh_* calls over a host transport on gloo
+        stepper = NativeTileMesh(spatial_index, tiling, halo, device=device, density_per_cell=density, flags=flags,
+                                 weights=weights, capacity_hint=capacity, rank=rank, n_ranks=world,
+                                 host_transport=TorchHostTransport(dist))
+        transport = f"cs_mesh_host_transport over torch.distributed ({backend}), staged through pinned host memory"
+    return stepper, stepper.tile(0), {"mesh": "native", "transport": transport,
+                                      "entry_point": "cs_mesh_step (include/crowdstep.h; lib.rs:195)"}
+
+
+def verify_mesh(args, ctx, stepper, mesh_kind, steps_made, fill, single_engine, grid, n_total, flags):
+    """The whole crowd of the mesh (collective: every rank gets it) against a single engine that rank 0 steps through
+    the same scene for the same number of steps: bit for bit."""
+    from rmf_crowdsim_amd import _abi
+    torch, dist, rank = ctx["torch"], ctx["dist"], ctx["rank"]
+    if mesh_kind != "native":
+        return {"mesh_equals_single_engine": None, "note": "--verify needs --mesh native (cs_mesh_read_agents gathers the crowd)"}
+    crowd = stepper.read_agents()
+    verdict = [None]
+    if rank == 0:
+        ref = single_engine(grid, n_total + 4096, flags & ~_abi.CS_CFG_TILE_OVERLAP)
+        made = fill(ref)
+        for _ in range(steps_made - made):
+            ref.step(0.05, report=False)
+        want = ref.read_agents()
+        same = len(want) == len(crowd) and want.tobytes() == crowd.tobytes()
+        verdict = [{"mesh_equals_single_engine": bool(same), "steps_compared": steps_made, "agents": int(len(want)),
+                    "agents_on_the_mesh": int(len(crowd))}]
+        del ref
+    dist.broadcast_object_list(verdict, src=0)
+    return verdict[0]
 
 
 def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
@@ -312,43 +414,31 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         flags |= _abi.CS_CFG_TILE_OVERLAP
 
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
-    from rmf_crowdsim_amd.tiles import DistributedTiles, default_tiling
+    from rmf_crowdsim_amd.tiles import default_tiling
+    arm, fail = ctx["arm"], ctx["fail"]
     lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
     n_sinks = 0
     tile_report = {}
     uniform_kind = args.workload in ("walk", "creep")
     crowd = {"hotspots": scenes.hotspot_crowd, "random": scenes.random_crowd}.get(args.workload)
     total_steps = steps + warmup + clock_warmup + 2
+    halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
+    hot = args.workload == "hotspots"
+    tiling = (1, 1) if world == 1 else default_tiling(world)
+    leg_name = f"{scaling}-scaling leg"
+
+    def single_engine(grid, capacity, engine_flags=flags):
+        return Simulation(LocationHash2D(**grid), device=device, flags=engine_flags,
+                          stream=torch.cuda.current_stream().cuda_stream, capacity_hint=capacity)
+
     if args.workload == "stream":
         # BASELINE.json configs[3]: the population is spawned and despawned by source-sinks; every
         # step runs the spawn kernel, the sink test and the compaction in the re-sort
         from rmf_crowdsim_amd import MonotonicCrowd, SourceSink, StubHighLevelPlan
         lanes, grid, fill_steps = scenes.stream_lanes(n_total, lane_length=16.0, cell_size=args.cell)
         extent = grid["width"]
-        if world == 1:
-            tiling = (1, 1)
-            sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
-                             stream=torch.cuda.current_stream().cuda_stream,
-                             capacity_hint=int(per_gpu * 1.2) + 4096)
-            stepper = sim
-        else:
-            tiling = default_tiling(world)
-            halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
-            stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
-                                       density_per_cell=1.5 * scenes.METRIC_DENSITY * args.cell ** 2,
-                                       capacity_hint=int(per_gpu * 1.3) + 4096, flags=flags)
-            sim = stepper.sim
-        plans = {}
-        if args.planner == "route":
-            from rmf_crowdsim_amd import RouteFollower
-            route_hlp = RouteFollower(lambda start, goal: [start, goal], scale=0.25, speed=scenes.WALK_SPEED)
-        for src, dst, vel in lanes:
-            hlp = route_hlp if args.planner == "route" else plans.setdefault(vel, StubHighLevelPlan(vel))
-            stepper.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False,
-                                               args.eyesight))
-        n_sinks = len(lanes)
-        for _ in range(fill_steps):
-            stepper.step(0.05, report=False)
+        pts = group = None
+        density, capacity, weights = 1.5 * scenes.METRIC_DENSITY * args.cell ** 2, int(per_gpu * 1.3) + 4096, None
         speed = scenes.WALK_SPEED
     else:
         if uniform_kind:
@@ -356,32 +446,65 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                 n_total, seed=7, cell_size=args.cell, room=walk_room(total_steps) if args.workload == "walk" else 0.0)
         else:
             pts, grid, extent, group = crowd(n_total, seed=7, cell_size=args.cell)
-        if world == 1:
-            tiling = (1, 1)
-            sim = Simulation(LocationHash2D(**grid), device=device, flags=flags,
-                             stream=torch.cuda.current_stream().cuda_stream, capacity_hint=per_gpu + 1024)
-            stepper = sim
-        else:
-            # one crowd of n_total agents, cut into spatial tiles, one tile per rank; every rank sees
-            # the global add_agents call and keeps the agents of its own cells
-            tiling = default_tiling(world)
-            halo = int(np.ceil(args.eyesight / args.cell - 1e-9))
-            hot = args.workload == "hotspots"
-            # a clustered crowd gets cuts at the quantiles of its row / column histograms; so does the
-            # walking crowd, which stands at the low-x end of its grid
-            stepper = DistributedTiles(LocationHash2D(**grid), tiling, halo, device,
-                                       density_per_cell=(3.0 if hot else 1.5) * scenes.METRIC_DENSITY * args.cell ** 2,
-                                       capacity_hint=int(per_gpu * (1.5 if hot else 1.15)) + 4096, flags=flags,
-                                       weights=pts if (hot or args.workload == "walk") else None)
-            sim = stepper.sim
-            counts = stepper.layout.tile_counts(pts, LocationHash2D(**grid))
-            tile_report = {"agents_per_tile": counts.reshape(-1).tolist(),
-                           "imbalance_max_over_mean": float(counts.max() / counts.mean())}
-        populate(stepper, args.workload, pts, group, speed, lp, args.eyesight)
+        density = (3.0 if hot else 1.5) * scenes.METRIC_DENSITY * args.cell ** 2
+        capacity = int(per_gpu * (1.5 if hot else 1.15)) + 4096
+        # a clustered crowd gets cuts at the quantiles of its row / column histograms; so does the
+        # walking crowd, which stands at the low-x end of its grid
+        weights = pts if (hot or args.workload == "walk") else None
+
+    def fill(target):
+        """The scene into a single engine or a mesh; returns the steps made while filling (stream workload)."""
+        if args.workload != "stream":
+            populate(target, args.workload, pts, group, speed, lp, args.eyesight)
+            return 0
+        plans = {}
+        if args.planner == "route":
+            from rmf_crowdsim_amd import RouteFollower
+            route_hlp = RouteFollower(lambda start, goal: [start, goal], scale=0.25, speed=scenes.WALK_SPEED)
+        for src, dst, vel in lanes:
+            hlp = route_hlp if args.planner == "route" else plans.setdefault(vel, StubHighLevelPlan(vel))
+            target.add_source_sink(SourceSink(src, 0.5, MonotonicCrowd(1000.0), hlp, lp, [dst], False, args.eyesight))
+        for _ in range(fill_steps):
+            target.step(0.05, report=False)
+        return fill_steps
+
+    steps_made = 0
+    if world == 1:
+        sim = single_engine(grid, (int(per_gpu * 1.2) if args.workload == "stream" else per_gpu) + 4096)
+        stepper = sim
+        mesh_kind = None
+    else:
+        # one crowd of n_total agents, cut into spatial tiles, one tile per rank; every rank sees the global
+        # add_agents call and keeps the agents of its own cells.  A rank that cannot set its tile up says where.
+        mesh_kind = args.mesh
+        arm(f"{leg_name}: mesh creation ({mesh_kind}; RCCL communicator init on the nccl backend)")
+        try:
+            stepper, sim, how = make_mesh(args, ctx, LocationHash2D(**grid), tiling, halo, density, capacity, flags, weights)
+        except Exception as err:  # noqa: BLE001 (whatever it is, the rank must leave with the phase named)
+            fail(f"{leg_name}: mesh creation ({mesh_kind})", err)
+        tile_report.update(how)
+        if pts is not None:
+            counts = TileCounts(LocationHash2D(**grid), tiling, weights, halo).of(pts)
+            tile_report.update({"agents_per_tile": counts.reshape(-1).tolist(),
+                                "imbalance_max_over_mean": float(counts.max() / counts.mean())})
+    n_sinks = len(lanes) if args.workload == "stream" else 0
+    arm(f"{leg_name}: populating the crowd")
+    try:
+        steps_made += fill(stepper)
+    except Exception as err:  # noqa: BLE001
+        fail(f"{leg_name}: populating the crowd", err)
+    if args.workload != "stream" and not args.verify:
         del pts, group
     if world > 1:
         tile_report["ranks_in_comm"] = dist.get_world_size()
         tile_report["devices_visible"] = torch.cuda.device_count()
+        # the first exchange with real peers, waited for: a transport that does not work fails HERE, by name
+        arm(f"{leg_name}: first halo exchange + step (waited for)")
+        try:
+            stepper.step(0.05, report=True)
+            steps_made += 1
+        except Exception as err:  # noqa: BLE001
+            fail(f"{leg_name}: first halo exchange + step", err)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -389,30 +512,48 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(clock_warmup + warmup):
-        stepper.step(0.05, report=False)
-    sim.synchronize()
+    def drain():
+        """Waits for the device and surfaces what fire-and-forget steps left behind (a mesh: agreed over the ranks)."""
+        (stepper if mesh_kind == "native" else sim).synchronize()
+
+    arm(f"{leg_name}: warm-up steps")
+    try:
+        for _ in range(clock_warmup + warmup):
+            stepper.step(0.05, report=False)
+        steps_made += clock_warmup + warmup
+        drain()
+    except Exception as err:  # noqa: BLE001
+        fail(f"{leg_name}: warm-up steps", err)
     sim.profile_reset()
     # hipEvents around K4 on the engine's stream; every 4th launch of the timed region, since an
-    # event pair costs the stream ~6 us per step
-    # (tiles: also the halo regions of the step, exchange and unpack in turn: an odd stride times both kinds)
-    sim.profile_stride(max(1, args.profile_stride | 1 if world > 1 else args.profile_stride))
-    sim.profile_enable((1 << _abi.CS_K_NEIGHBOUR_FORCE) | ((1 << _abi.CS_K_HALO) if world > 1 else 0))
+    # event pair costs the stream ~6 us per step.  Tiles: every phase of the step by itself (pack, exchange, unpack,
+    # border / interior launch, scan, scatter), each kind with its own stride counter.
+    sim.profile_stride(max(1, args.profile_stride))
+    sim.profile_enable(((1 << _abi.CS_K_COUNT) - 1) if world > 1 else (1 << _abi.CS_K_NEIGHBOUR_FORCE))
+    arm(f"{leg_name}: timed region")
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        stepper.step(0.05, report=False)
-        if args.readback:  # frame k is fetched while step k + 1 runs
+    try:
+        for _ in range(steps):
+            stepper.step(0.05, report=False)
+            if args.readback:  # frame k is fetched while step k + 1 runs
+                sim.snapshot(wait=True)
+                sim.request_snapshot()
+        if args.readback:
             sim.snapshot(wait=True)
-            sim.request_snapshot()
-    if args.readback:
-        sim.snapshot(wait=True)
+    except Exception as err:  # noqa: BLE001
+        fail(f"{leg_name}: timed region", err)
     sync_all()
     elapsed = time.perf_counter() - t0
+    steps_made += steps
     sim.profile_enable(0)
     prof = sim.profile_read()
-    if not args.debug:
-        sim.synchronize()  # surfaces "Index out of bounds" if any step left the grid
+    arm(f"{leg_name}: after the timed region (error check, report step)")
+    try:
+        if not args.debug:
+            drain()  # surfaces "Index out of bounds" if any step left the grid
+    except Exception as err:  # noqa: BLE001
+        fail(f"{leg_name}: a step of the timed region failed", err)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
@@ -424,7 +565,8 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         rep = {"n_tti_zero": -1, "n_nonfinite": -1, "n_agents": per_gpu}
     else:
         stepper.step(0.05, report=True)
-        rep = sim.last_report
+        steps_made += 1
+        rep = stepper.last_report if mesh_kind == "native" else sim.last_report
     total_agents = n_total
     t_n = torch.tensor([rep["n_agents"], rep["n_tti_zero"], rep["n_nonfinite"]], dtype=torch.int64,
                        device="cuda" if backend == "nccl" else "cpu")
@@ -437,10 +579,27 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         raise SystemExit(f"bench: {alive_all} of {n_total} agents alive after the run")
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
-    if world > 1 and prof["halo"]["launches"]:
-        # rank 0's halo exchange + unpack per step, device time between hipEvents on the engine's stream (with
-        # --overlap the exchange runs on the second stream and what is seen here is the wait for it)
-        tile_report["halo_ms_per_step_rank0"] = 2.0 * prof["halo"]["total_ms"] / prof["halo"]["launches"]
+    if world > 1:
+        # every phase of a tile's step, device time between hipEvents on the stream the phase ran on: rank 0's and the
+        # slowest rank's (the exchange includes the wait for the slowest peer: that is what the step pays)
+        names = list(_abi.KERNEL_NAMES)
+        us = torch.tensor([1e3 * prof[k]["total_ms"] / prof[k]["launches"] if prof[k]["launches"] else 0.0 for k in names],
+                          dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        us_max = us.clone()
+        dist.all_reduce(us_max, op=dist.ReduceOp.MAX)
+        tile_report["phase_us_rank0"] = {k: round(float(v), 2) for k, v in zip(names, us.tolist()) if v > 0}
+        tile_report["phase_us_max_over_ranks"] = {k: round(float(v), 2) for k, v in zip(names, us_max.tolist()) if v > 0}
+        tile_report["phase_us_note"] = ("neighbour_force spans step_border + step_interior when the launch is split "
+                                        "(--overlap); halo_pack is absent when the step kernel packed; with --overlap the "
+                                        "exchange runs on the second stream, beside step_interior")
+        if mesh_kind == "native":
+            tile_report["exchange_bytes_per_step_rank0"] = stepper.exchange_bytes
+            tile_report["exchanges_ahead"] = sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD)
+            tile_report["exchanges_ahead_used"] = sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD_USED)
+    if args.verify and world > 1:
+        arm(f"{leg_name}: --verify (mesh == single engine)")
+        tile_report["verify"] = verify_mesh(args, ctx, stepper, mesh_kind, steps_made, fill, single_engine, grid,
+                                            n_total, flags)
     leg = {"value": total_agents * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "total_agents": total_agents,
            "per_gpu": per_gpu, "steps": steps, "k4_ms": k4_ms, "tile_report": tile_report}
     if not headline:
@@ -490,32 +649,44 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         except (OSError, KeyError, ValueError):
             continue
 
-    # the creep scene beside the walking one (same crowd, standing, NON-ZERO forces: in the walking scene the
-    # force term is computed in full and underflows to exactly 0)
-    creep_leg = None
+    # Two more scenes timed beside the walking one, in the same run: the creep scene (same crowd, standing, NON-ZERO
+    # forces: in the walking scene the force term is computed in full and underflows to exactly 0)
+    # and the scattered crowd (a randomly thinned lattice: neighbour counts scatter like a real crowd's, forces of
+    # every size), the dearest member of the family at this density.
+    side_legs = {}
     if rank == 0 and world == 1 and args.workload == "walk" and not args.no_creep_leg and not args.debug:
         del stepper, sim
-        c_sim, _, _ = build_crowd(Simulation, per_gpu, args.cell, args.eyesight, speed, workload="creep",
-                                  device=device, stream=torch.cuda.current_stream().cuda_stream, capacity=per_gpu + 1024)
-        for _ in range(max(10, warmup + clock_warmup)):  # the same untimed steps as the headline leg (the clocks
-            c_sim.step(0.05, report=False)                # have dropped while the host built this crowd)
-        c_sim.synchronize()
-        c_sim.profile_reset()
-        c_sim.profile_stride(4)
-        c_sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        for _ in range(40):
-            c_sim.step(0.05, report=False)
-        torch.cuda.synchronize()
-        c_el = time.perf_counter() - c0
-        c_sim.profile_enable(0)
-        cp = c_sim.profile_read()["neighbour_force"]
-        c_sim.step(0.05, report=True)
-        creep_leg = {"workload": "creep", "kernel_ms": cp["total_ms"] / max(cp["launches"], 1), "ms_per_step": c_el / 40 * 1e3,
-                     "value": per_gpu * 40 / c_el, "steps": 40, "n_tti_zero": c_sim.last_report["n_tti_zero"],
-                     "n_nonfinite": c_sim.last_report["n_nonfinite"]}
-        del c_sim
+        for name in ("creep", "random"):
+            if name == "creep":
+                c_sim, _, _ = build_crowd(Simulation, per_gpu, args.cell, args.eyesight, speed, workload="creep",
+                                          device=device, stream=torch.cuda.current_stream().cuda_stream, capacity=per_gpu + 1024)
+            else:
+                r_pts, r_grid, _, r_group = scenes.random_crowd(per_gpu, seed=7, cell_size=args.cell)
+                c_sim = Simulation(LocationHash2D(**r_grid), device=device, flags=flags,
+                                   stream=torch.cuda.current_stream().cuda_stream, capacity_hint=per_gpu + 1024)
+                populate(c_sim, "random", r_pts, r_group, speed, lp, args.eyesight)
+                del r_pts, r_group
+            for _ in range(max(10, warmup + clock_warmup)):  # the same untimed steps as the headline leg (the clocks
+                c_sim.step(0.05, report=False)                # have dropped while the host built this crowd)
+            c_sim.synchronize()
+            c_sim.profile_reset()
+            c_sim.profile_stride(4)
+            c_sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for _ in range(40):
+                c_sim.step(0.05, report=False)
+            torch.cuda.synchronize()
+            c_el = time.perf_counter() - c0
+            c_sim.profile_enable(0)
+            cp = c_sim.profile_read()["neighbour_force"]
+            c_sim.step(0.05, report=True)
+            side_legs[name] = {"workload": name, "kernel_ms": cp["total_ms"] / max(cp["launches"], 1),
+                               "ms_per_step": c_el / 40 * 1e3, "value": per_gpu * 40 / c_el, "steps": 40,
+                               "n_tti_zero": c_sim.last_report["n_tti_zero"], "n_nonfinite": c_sim.last_report["n_nonfinite"],
+                               "scene_stats": scene_stats(name, per_gpu, args)}
+            del c_sim
+    creep_leg = side_legs.get("creep")
 
     if rank == 0:
         ceiling = valu_ceiling()
@@ -556,6 +727,10 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                 # (48 B per agent + 8 B per cell)
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                # the figure north_star's target is stated in: the kernel's algorithmic READ bytes alone (32 B per
+                # agent: position, velocity, own preferred velocity, id, group) against the HBM peak
+                "hbm_read_frac": (agents_here * K4_READ_BYTES / (k4_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k4_ms > 0 else 0.0,
+                "hbm_read_target_frac": 0.40,
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
                 "kernel_ms": k4_ms, "kernel_launches_timed": k4["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -575,10 +750,13 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                         "PMC summary taken on exactly these sources and this workload is cached under profiles/",
             },
         }
+        out["scene_stats"] = scene_stats(args.workload, per_gpu, args)
         if creep_leg:
             out["creep_scene"] = creep_leg
             # the same crowd with forces that do not underflow: the figure to quote when the force path must count
             out["value_full_force"] = creep_leg["value"]
+        if "random" in side_legs:
+            out["scattered_scene"] = side_legs["random"]
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would wait for it)
             wl = args.workload if uniform_kind else "creep"
             out["cpu_baseline"] = cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)
@@ -587,6 +765,24 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                 out["cpu_baseline_openmp"] = cpu_baseline_openmp(per_gpu, args.cell, args.eyesight, speed, workload=wl)
         leg["line"] = out
     return leg
+
+
+def scene_stats(workload, agents, args):
+    """What the neighbour pass of a scene consists of, measured offline with the kernel's trip counters (a
+    -DCS_TILE_TRIPS build, tools/trip_counts.py) and cached under profiles/rNN/scene_stats.json: mean neighbours in
+    sight, mean neighbours an agent yields to (the force terms that are not identically 0), the share of agents with a
+    finite time to collision (whose force pass runs at all), loop trips per wave.  Keyed like k4_traffic.json: a
+    summary taken on other sources or another scene reads as null."""
+    key = profile_key(f"scene {workload} agents {agents} cell {args.cell} eyesight {args.eyesight}")
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "scene_stats.json")) as f:
+                table = json.load(f)
+            if key in table:
+                return {**table[key], "source": f"profiles/{rnd}/scene_stats.json", "profile_key": key}
+        except (OSError, ValueError):
+            continue
+    return {"profile_key": key, "note": "no cached trip-counter summary for these sources and this scene"}
 
 
 def valu_ceiling():

@@ -357,8 +357,16 @@ enum {
   CS_K_SCAN = 1,            /* exclusive scan of cell counts (K2)        */
   CS_K_SCATTER = 2,         /* reorder into cell order (K3)              */
   CS_K_SPAWN = 3,           /* source occupancy + append (K6)            */
-  CS_K_HALO = 4,            /* halo pack/unpack (K7)                     */
-  CS_K_COUNT = 5
+  CS_K_HALO = 4,            /* halo pack/unpack of the two-phase schedule (K7: cs_halo_pack / cs_halo_unpack) */
+  /* the phases of a tile's step in the one-phase schedule (cs_tile_step_rccl, cs_mesh_step), each timed by itself: */
+  CS_K_HALO_PACK = 5,       /* cs_halo_pack_all's launch (none when the step kernel packed: the usual case)     */
+  CS_K_HALO_EXCHANGE = 6,   /* cs_halo_exchange_rccl: the ncclSend / ncclRecv group, on the stream it was issued on
+                             * (the second stream for an exchange made ahead under CS_CFG_TILE_OVERLAP)           */
+  CS_K_HALO_UNPACK = 7,     /* cs_halo_unpack_all's launch                                                       */
+  CS_K_STEP_BORDER = 8,     /* CS_CFG_TILE_OVERLAP: the neighbour kernel's launch over the windows along the
+                             * tile's edges (on the second stream when the exchange follows it there) ...        */
+  CS_K_STEP_INTERIOR = 9,   /* ... and over the interior windows (CS_K_NEIGHBOUR_FORCE spans both)               */
+  CS_K_COUNT = 10
 };
 /* Per-kernel hipEvent timing: bit k of kernel_mask times kernel CS_K_k (events are
  * recorded on the engine's stream around each launch); 0 turns timing off. */
@@ -488,7 +496,8 @@ int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
  * The multi-tile form of `Simulation` (lib.rs:69-192): layout (tensor-product cuts, even or at the quantiles of a
  * set of positions), one tile engine per tile, halo buffers sized per direction, the exchange, the spawn flags OR-ed
  * over the tiles, route-cache misses, re-cuts and merged spatial queries.  Results equal the single engine's bit
- * for bit on scenes that stay clear of the domain's edges (a tile's grid edges are strict).
+ * for bit, the reference's clamp into row / column 0 along the domain's own low edges included
+ * (location_hash_2d.rs:54-66); what a mesh does not reproduce is the alias of y beyond the row stride (Err here).
  *   rccl_unique_id null   every tile in this process on ONE device (exchanges are device copies on a shared stream)
  *   rccl_unique_id given  one tile per rank (n_ranks = tiles_x * tiles_y, also 1 x 1 with one rank), rank = tile index = tx * tiles_y + ty, halo records over RCCL from the
  *                  engine itself (ncclSend / ncclRecv for the halos, ncclAllReduce for the spawn flags,
@@ -500,7 +509,13 @@ int cs_tile_step_rccl(cs_engine*, double dt_seconds, cs_step_report* report);
  * rank), cs_mesh_remove_agent and multi-leg route followers work across ranks.
  *                  Every rank passes the same grid and the same descriptor but for `rank` and the device: layout
  *                  and halo capacities are computed from them on each rank and are not exchanged.
- * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics). */
+ * cs_mesh_tile gives the underlying tile engines (profiling, snapshots, kernel statistics).
+ * Failure: a step that fails on ANY tile (lib.rs:299-302: "Index out of bounds") stops the whole mesh: the step phase
+ * still runs on every local tile, the ranks of a distributed mesh agree that somebody failed before anybody leaves
+ * the schedule (after the step when the host waits for it anyway, i.e. with a report, listeners or host planners;
+ * every 32 steps and in cs_mesh_synchronize when steps are made without waiting for the device), and from then on
+ * every call on every rank returns the first error (the failing rank's own, "a tile of this mesh failed ..." elsewhere).
+ * Between its failure and the agreed check a rank keeps issuing the collectives of its steps and nothing else. */
 typedef struct cs_mesh cs_mesh;
 /* A transport the HOST brings (MPI, gloo, sockets) for a distributed mesh: instead of RCCL (rccl_unique_id null:
  * the halo records and the spawn flags go through it, staged in pinned host memory), or beside it (both given:
@@ -560,6 +575,8 @@ int cs_mesh_synchronize(cs_mesh*);
 size_t cs_mesh_agent_count(cs_mesh*);      /* the whole crowd (distributed forms: collective) */
 size_t cs_mesh_read_agents(cs_mesh*, cs_agent_view* out, size_t cap);             /* ascending id; SIZE_MAX on error */
 int cs_mesh_tile_counts(cs_mesh*, uint64_t* out_per_local_tile);
+/* bytes the local tiles send per halo exchange, i.e. per step (fixed-capacity buffers: independent of the crowd) */
+uint64_t cs_mesh_exchange_bytes(const cs_mesh*);
 int cs_mesh_recut(cs_mesh*);
 int cs_mesh_query_radius_batch(cs_mesh*, size_t n, const double* xy, const double* radius, size_t cap_per_query,
                                uint64_t* out_ids, uint64_t* out_counts);          /* spatial_index.rs:4-14 */

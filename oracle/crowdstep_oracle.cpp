@@ -1202,6 +1202,7 @@ int cs_mesh_tile_counts(cs_mesh* m, uint64_t* out) {
   out[0] = cs_agent_count(m->e);
   return 0;
 }
+uint64_t cs_mesh_exchange_bytes(const cs_mesh*) { return 0; }  // (one process: nothing travels)
 int cs_mesh_recut(cs_mesh*) { return 0; }  // (nothing to cut)
 int cs_mesh_query_radius_batch(cs_mesh* m, size_t n, const double* xy, const double* radius, size_t cap, uint64_t* out_ids,
                                uint64_t* out_counts) {

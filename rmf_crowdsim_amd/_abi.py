@@ -21,8 +21,10 @@ CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK, CS_HLP_ROUTE = 
 CS_ROUTE_MAX_WAYPOINTS = 1023
 CS_GEN_MONOTONIC, CS_GEN_POISSON_SEEDED, CS_GEN_CALLBACK = 0, 1, 2
 CS_EVENT_SPAWNED, CS_EVENT_DESTROYED = 1, 2
-(CS_K_NEIGHBOUR_FORCE, CS_K_SCAN, CS_K_SCATTER, CS_K_SPAWN, CS_K_HALO, CS_K_COUNT) = range(6)
-KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo"]
+(CS_K_NEIGHBOUR_FORCE, CS_K_SCAN, CS_K_SCATTER, CS_K_SPAWN, CS_K_HALO, CS_K_HALO_PACK, CS_K_HALO_EXCHANGE,
+ CS_K_HALO_UNPACK, CS_K_STEP_BORDER, CS_K_STEP_INTERIOR, CS_K_COUNT) = range(11)
+KERNEL_NAMES = ["neighbour_force", "scan", "scatter", "spawn", "halo", "halo_pack", "halo_exchange", "halo_unpack",
+                "step_border", "step_interior"]
 CS_DIR_XLO, CS_DIR_XHI, CS_DIR_YLO, CS_DIR_YHI = 0, 1, 2, 3
 CS_DIR_XLO_YLO, CS_DIR_XLO_YHI, CS_DIR_XHI_YLO, CS_DIR_XHI_YHI = 4, 5, 6, 7
 CS_HALO_RECORD_BYTES = 40
@@ -230,6 +232,7 @@ SYMBOLS = {
     "cs_mesh_agent_count": (C.c_size_t, [C.c_void_p]),
     "cs_mesh_read_agents": (C.c_size_t, [C.c_void_p, C.POINTER(AgentView), C.c_size_t]),
     "cs_mesh_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cs_mesh_exchange_bytes": (C.c_uint64, [C.c_void_p]),
     "cs_mesh_recut": (C.c_int, [C.c_void_p]),
     "cs_mesh_query_radius_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

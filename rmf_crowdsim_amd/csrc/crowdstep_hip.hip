@@ -1037,7 +1037,7 @@ static int halo_exchange_rccl_on(cs_engine* e, int32_t axis, hipStream_t stream)
     e->error = "cs_halo_exchange_rccl: axis is 0, 1 or negative (all eight directions)";
     return 3;
   }
-  e->prof_begin(CS_K_HALO);
+  const int timed = e->prof_open_on(CS_K_HALO_EXCHANGE, stream);
   bool good = rccl_api::ok(e, a.group_start(), "ncclGroupStart");
   for (int d = d0; good && d < d1; ++d) {
     const cs_engine::HaloDir& h = e->halo[d];
@@ -1047,7 +1047,7 @@ static int halo_exchange_rccl_on(cs_engine* e, int32_t axis, hipStream_t stream)
            rccl_api::ok(e, a.recv(h.recv, bytes, rccl_api::kUint8, e->halo_peer[d], e->rccl_comm, stream), "ncclRecv");
   }
   const int end_rc = a.group_end();  // always close the group
-  e->prof_end();
+  e->prof_close_on(timed, stream);
   if (!good) return 8;
   return rccl_api::ok(e, end_rc, "ncclGroupEnd") ? 0 : 8;
 }
@@ -1068,14 +1068,19 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int* values_dev, size_t n) {
 // host: halo pack -> RCCL exchange -> unpack -> (source-sinks: device-side probe, all-reduce of the
 // flags, commit) -> cs_step.  For hosts without listeners, host planners or multi-leg route sinks
 // (those need the split calls: events must reach the host between the phases).
+// e->step_colls tells which of the step's collectives this call has issued (bit 0: the halo exchange, bit 1: the
+// all-reduce of the spawn flags): a mesh whose tile fails half way issues the missing ones itself, so that the other
+// ranks' collectives still find their partner (cs_mesh.hip.inc: mesh_zombie_step).
 int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
   hipSetDevice(e->device);
+  e->step_colls = 0;
   if (!e->tile) {
     e->error = "cs_tile_step_rccl needs a tile engine";
     return 3;
   }
   if (int rc = e->halo_pack_all()) return rc;
   if (int rc = cs_halo_exchange_rccl(e, -1)) return rc;
+  e->step_colls |= 1u;
   if (int rc = e->halo_unpack_all()) return rc;
   if (int rc = e->upload_sinks()) return rc;
   if (int rc = e->upload_groups()) return rc;
@@ -1087,15 +1092,10 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
       return 3;
     }
     const size_t ns = e->sinks.size();
-    if (ns > e->step_flags_cap) {
-      HIP_OK_E(e, hipStreamSynchronize(e->stream));
-      hipFree(e->step_flags_dev);
-      e->step_flags_dev = nullptr;
-      e->step_flags_cap = ns * 2 + 64;
-      HIP_OK_E(e, hipMalloc(&e->step_flags_dev, e->step_flags_cap * sizeof(int)));
-    }
+    if (int rc = e->reserve_step_flags(ns)) return rc;
     if (int rc = e->spawn_probe_dev(dt_seconds, e->step_flags_dev)) return rc;
     if (int rc = cs_allreduce_max_i32_rccl(e, e->step_flags_dev, ns)) return rc;
+    e->step_colls |= 2u;
     if (int rc = e->spawn_commit_dev(e->step_flags_dev)) return rc;
   }
   // CS_CFG_TILE_OVERLAP: the step puts the border windows' launch on the second stream; the next
@@ -1112,6 +1112,29 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
     e->n_exchanges_ahead += 1;
   }
   return rc;
+}
+
+// The collectives of one cs_tile_step_rccl and nothing else: what a tile that has FAILED issues in the place of its
+// steps until the ranks of its mesh have agreed that the run is over (the others' ncclSend / ncclRecv / ncclAllReduce
+// would wait for it for ever: RCCL has no timeout).  `done`: the collectives a failed cs_tile_step_rccl call issued
+// before it gave up (cs_engine::step_colls), 0 for a whole step.  The records that travel are whatever the send
+// buffers hold; nobody steps on them.
+static int tile_zombie_collectives(cs_engine* e, uint32_t done) {
+  hipSetDevice(e->device);
+  if (!(done & 1u)) {
+    if (e->exchanged_ahead) {  // (made by the last good step, on the second stream: it IS this step's exchange)
+      e->exchanged_ahead = false;
+      if (hipStreamWaitEvent(e->stream, e->ev_xchg, 0) != hipSuccess) return 90;
+    } else if (int rc = halo_exchange_rccl_on(e, -1, e->stream)) {
+      return rc;
+    }
+  }
+  if (!(done & 2u) && !e->sinks.empty()) {
+    const size_t ns = e->sinks.size();
+    if (int rc = e->reserve_step_flags(ns)) return rc;
+    if (int rc = cs_allreduce_max_i32_rccl(e, e->step_flags_dev, ns)) return rc;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -376,9 +376,23 @@ class Simulation:
     def _load_library(self):
         return _native.load()
 
+    @classmethod
+    def borrowed(cls, lib, engine, spatial_index=None):
+        """A view of an engine somebody else owns (a tile of a mesh, cs_mesh_tile): profiling, kernel statistics,
+        snapshots, queries of that tile.  Closing the view leaves the engine alone."""
+        self = cls.__new__(cls)
+        self._lib, self._engine, self._borrowed = lib, engine, True
+        self.spatial_index = spatial_index
+        self._planner_handles, self._planners_alive = {}, []
+        self._host_lps, self._host_lp_of_agent, self._host_lp_of_sink = False, {}, {}
+        self._listeners, self._next_listener, self._source_sinks = {}, 0, {}
+        self._agents_cache, self.last_report = None, None
+        return self
+
     def close(self):
         if getattr(self, "_engine", None):
-            self._lib.cs_destroy(self._engine)
+            if not getattr(self, "_borrowed", False):
+                self._lib.cs_destroy(self._engine)
             self._engine = None
 
     def __del__(self):

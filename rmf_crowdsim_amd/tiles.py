@@ -579,6 +579,19 @@ class NativeTileMesh:
         if self._lib.cs_mesh_synchronize(self._mesh) != 0:
             raise self._err()
 
+    def tile(self, local_index=0):
+        """The engine of a local tile as a (borrowed) Simulation: profiling, kernel statistics, snapshots."""
+        from .simulation import Simulation
+        engine = self._lib.cs_mesh_tile(self._mesh, int(local_index))
+        if not engine:
+            raise IndexError(local_index)
+        return Simulation.borrowed(self._lib, engine)
+
+    @property
+    def exchange_bytes(self):
+        """Bytes the local tiles send per halo exchange (fixed-capacity buffers)."""
+        return int(self._lib.cs_mesh_exchange_bytes(self._mesh))
+
     def recut(self):
         if self._lib.cs_mesh_recut(self._mesh) != 0:
             raise self._err()

@@ -42,7 +42,12 @@ pub const CS_K_SCAN: u32 = 1;
 pub const CS_K_SCATTER: u32 = 2;
 pub const CS_K_SPAWN: u32 = 3;
 pub const CS_K_HALO: u32 = 4;
-pub const CS_K_COUNT: u32 = 5;
+pub const CS_K_HALO_PACK: u32 = 5;
+pub const CS_K_HALO_EXCHANGE: u32 = 6;
+pub const CS_K_HALO_UNPACK: u32 = 7;
+pub const CS_K_STEP_BORDER: u32 = 8;
+pub const CS_K_STEP_INTERIOR: u32 = 9;
+pub const CS_K_COUNT: u32 = 10;
 
 pub const CS_DIR_XLO: u32 = 0;
 pub const CS_DIR_XHI: u32 = 1;
@@ -331,6 +336,7 @@ extern "C" {
     pub fn cs_mesh_agent_count(m: *mut cs_mesh) -> usize;
     pub fn cs_mesh_read_agents(m: *mut cs_mesh, out: *mut cs_agent_view, cap: usize) -> usize;
     pub fn cs_mesh_tile_counts(m: *mut cs_mesh, out_per_local_tile: *mut u64) -> c_int;
+    pub fn cs_mesh_exchange_bytes(m: *const cs_mesh) -> u64;
     pub fn cs_mesh_recut(m: *mut cs_mesh) -> c_int;
     pub fn cs_mesh_query_radius_batch(m: *mut cs_mesh, n: usize, xy: *const f64, radius: *const f64, cap_per_query: usize, out_ids: *mut u64, out_counts: *mut u64) -> c_int;
     pub fn cs_mesh_query_knn_batch(m: *mut cs_mesh, n: usize, xy: *const f64, k: usize, out_ids: *mut u64, out_counts: *mut u64) -> c_int;

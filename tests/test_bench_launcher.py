@@ -53,21 +53,60 @@ def test_launcher_is_a_no_op_under_a_launcher(monkeypatch):
     assert bench.launch_ranks_if_needed(A()) is None  # returns instead of spawning
 
 
-@pytest.mark.gpu
-def test_bench_gpus_2_as_a_plain_command():
-    """The driver's command shape without its launcher: two ranks (gloo transport, one shared GPU),
-    strong scaling = 200k agents in all, the weak-scaled leg beside it."""
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "200000", "--steps", "10", "--warmup", "3",
-                        "--clock-warmup", "5", "--no-cpu-baseline"], env=_env(CS_BENCH_BACKEND="gloo"),
-                       capture_output=True, text=True, timeout=600)
+def _bench_line(p):
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_steps_the_native_mesh_and_it_equals_the_single_engine():
+    """The driver's command shape without its launcher: two ranks (ranks sharing the one GPU, so the cs_mesh_* calls
+    go over the gloo host transport), strong scaling = 200k agents in all, the weak-scaled leg beside it.  What is
+    stepped is the C ABI's mesh (one cs_mesh_step per step), and after the timed region of either leg the whole crowd
+    of the mesh equals a single engine stepped through the same scene, bit for bit (--verify)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "200000", "--steps", "10", "--warmup", "3",
+                        "--clock-warmup", "5", "--no-cpu-baseline", "--verify"], env=_env(CS_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=900)
+    line = _bench_line(p)
     assert line["n_gpus"] == 2
     assert line["scaling"] == "strong"
-    assert line["config"]["agents_total"] == 200000 and line["config"]["agents_per_gpu"] == 100000
-    assert line["config"]["ranks_in_comm"] == 2
+    cfg = line["config"]
+    assert cfg["mesh"] == "native" and cfg["entry_point"].startswith("cs_mesh_step")
+    assert cfg["agents_total"] == 200000 and cfg["agents_per_gpu"] == 100000
+    assert cfg["ranks_in_comm"] == 2
+    assert cfg["verify"]["mesh_equals_single_engine"] is True and cfg["verify"]["agents"] == 200000
+    assert cfg["verify"]["steps_compared"] == 10 + 3 + 5 + 2   # first exchange, clock warm-up, warm-up, timed, report
+    assert cfg["exchange_bytes_per_step_rank0"] > 0
+    phases = cfg["phase_us_rank0"]
+    assert phases["neighbour_force"] > 0 and phases["halo_unpack"] > 0 and phases["scan"] > 0 and phases["scatter"] > 0
     assert line["weak_scaled"]["agents_total"] == 400000
+    assert line["weak_scaled"]["verify"]["mesh_equals_single_engine"] is True
     assert line["value"] > 0 and line["weak_scaled"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_python_mesh_for_comparison():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "100000", "--steps", "5", "--warmup", "2",
+                        "--clock-warmup", "3", "--no-cpu-baseline", "--mesh", "python", "--no-second-scaling-leg"],
+                       env=_env(CS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    line = _bench_line(p)
+    assert line["config"]["mesh"] == "python" and line["n_gpus"] == 2 and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_a_rank_that_cannot_set_up_its_transport_says_where_and_exits_non_zero():
+    """RCCL refuses two ranks on one device; with the device check bypassed the native mesh's communicator init (or
+    the first exchange) fails: every rank must leave with a non-zero code and the phase named, not hang."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "20000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--watchdog", "120"], env=_env(CS_BENCH_SHARE_DEVICE="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    assert "FAILED in phase" in err or "made no progress" in err, err[-3000:]
+    assert "process group init" in err or "mesh creation" in err or "first halo exchange" in err, err[-3000:]
 
 
 @pytest.mark.gpu

@@ -244,3 +244,112 @@ def test_config4_four_million_agents_with_hotspots():
     force = np.hypot(tiled["vx"], np.abs(tiled["vy"]) - scenes.CREEP_SPEED)
     assert np.mean(force > 0) > 0.9
     assert counts.max() / counts.mean() < 1.2
+
+
+# ---- long enough to cross the cuts (review of round 3: the full-size runs above make 2-3 steps) ----------------
+def test_config2_one_million_walkers_cross_every_cut_for_200_steps():
+    """configs[2] as it is benchmarked: the 1M-agent crowd WALKING at 1.3 m/s (6.5 cm per step) on a 4 x 2 mesh, 200
+    steps = 13 m: every agent changes cell about six times, tens of thousands migrate over a cut, the ghost rings are
+    refilled 200 times.  The mesh behind the C ABI (cs_mesh_*), the Python mesh, the tiled and the gather kernel of one
+    engine: the same bits; nobody lost or duplicated; the walkers walked."""
+    import bench
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+    n, steps = 1_000_000, 200
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0, room=bench.walk_room(steps))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    index = LocationHash2D(**grid)
+
+    def run(target):
+        ids = scenes.add_walking_crowd(target, pts, group, lp, 2.0)
+        for k in range(steps):
+            target.step(0.05, report=False)
+        return target.read_agents(), ids
+
+    tiled, ids = run(Simulation(index, flags=2, capacity_hint=n + 1024))
+    gather, _ = run(Simulation(index, flags=1, capacity_hint=n + 1024))
+    assert len(tiled) == n and (tiled["id"] == np.arange(n)).all()
+    assert tiled.tobytes() == gather.tobytes()
+    del gather
+    native_mesh = NativeTileMesh(index, (4, 2), 1, density_per_cell=15.0, weights=pts, capacity_hint=160_000)
+    rects = native_mesh.tile_rects()
+    native, _ = run(native_mesh)
+    assert tiled.tobytes() == native.tobytes()
+    del native, native_mesh
+    local, _ = run(LocalTileMesh(index, (4, 2), halo_cells=1, density_per_cell=15.0, weights=pts, capacity_hint=160_000))
+    assert tiled.tobytes() == local.tobytes()
+    assert np.isfinite(tiled["x"]).all() and np.isfinite(tiled["vx"]).all()
+    start = np.empty_like(pts)
+    start[np.asarray(ids)] = pts
+    walked = tiled["x"] - start[:, 0]
+    assert abs(float(walked.mean()) - steps * 0.05 * scenes.WALK_SPEED) < 1e-3 and float(walked.min()) > 12.9
+    # agents that crossed an x cut of the mesh (cell rows cx0 of tiles 1..3): thousands per cut
+    cuts = sorted(set(int(r[0]) for r in rects if r[0] > 0))
+    cut_x = [grid["offset"][0] + c * 2.0 for c in cuts]
+    crossed = [int(((start[:, 0] < x) & (tiled["x"] >= x)).sum()) for x in cut_x]
+    print(f"configs[2], 200 steps walking: crossed the x cuts at {cut_x}: {crossed}")
+    assert len(cuts) == 3 and min(crossed) > 10_000
+
+
+def test_config4_four_million_agents_50_steps_with_a_recut():
+    """configs[4] at full size for 52 steps, the crowd walking (3.4 m: agents leave and enter the hotspots' cells and
+    cross the weighted cuts), one re-cut of the running mesh at step 25.  The mesh behind the C ABI == one engine, bit
+    for bit, at the re-cut and at the end."""
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+    n, steps = 4_000_000, 52
+    pts, grid, extent, group = scenes.hotspot_crowd(n, seed=7, cell_size=2.0)
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    index = LocationHash2D(**grid)
+    single = Simulation(index, flags=2 | _abi.CS_CFG_DENSE, capacity_hint=n + 1024)
+    mesh = NativeTileMesh(index, (4, 2), 1, density_per_cell=30.0, flags=_abi.CS_CFG_DENSE, capacity_hint=700_000)  # even cuts first
+    for t in (single, mesh):
+        scenes.add_walking_crowd(t, pts, group, lp, 2.0, creep=scenes.CREEP_SPEED * 0.1)
+    before = mesh.tile_counts()
+    for k in range(steps):
+        if k == 25:
+            assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+            after = mesh.recut()
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    a, b = single.read_agents(), mesh.read_agents()
+    print(f"configs[4], {steps} steps walking, re-cut at 25: max/mean {before.max() / before.mean():.3f} -> "
+          f"{after.max() / after.mean():.3f}")
+    assert len(a) == n and (a["id"] == np.arange(n)).all() and a.tobytes() == b.tobytes()
+    assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
+    assert after.sum() == n and after.max() / after.mean() < 1.2 < before.max() / before.mean()
+    single.step(0.05)
+    assert single.last_report["n_agents"] == n and single.last_report["n_nonfinite"] == 0
+
+
+def test_config1_walking_crowd_1000_steps_against_the_f64_path():
+    """The default bench workload (the crowd walking at 1.3 m/s, scenes.add_walking_crowd) at configs[1]'s 100,000
+    agents for the north star's 1000 steps (65 m: every agent changes cell ~32 times) against the f64 CPU path
+    (oracle_fast_steps, bit-identical to the reference-shaped oracle): positions within 1e-4 of the extent."""
+    import os
+    import bench
+    from oracle_sim import fast_steps
+    n, steps = 100_000, 1000
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0, room=bench.walk_room(steps))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    speed = min(scenes.CREEP_SPEED, 0.25 / (steps + 2))   # bench.py's rule: at most 2.5 cm of closing over the run
+    sim = Simulation(LocationHash2D(**grid))
+    ids = np.asarray(scenes.add_walking_crowd(sim, pts, group, lp, 2.0, creep=speed))
+    for k in range(steps - 1):
+        sim.step(0.05, report=False)
+    sim.step(0.05)
+    assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0 and sim.last_report["n_agents"] == n
+    a = sim.read_agents()
+    by_id = np.empty_like(pts)
+    by_id[ids] = pts
+    pref = np.zeros_like(pts)
+    pref[:, 0] = scenes.WALK_SPEED
+    pref[ids, 1] = np.where(group == 0, speed, -speed)
+    struck = np.zeros(n, dtype=np.uint8)
+    xy, vel, sec = fast_steps(by_id, pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, steps,
+                              threads=min(16, os.cpu_count() or 1), spurious=struck)
+    ok = np.isfinite(xy).all(axis=1)
+    assert np.isfinite(a["x"]).all() and ((~ok) == (struck != 0)).all() and (~ok).sum() <= 60
+    dp = np.hypot(a["x"] - xy[:, 0], a["y"] - xy[:, 1])[ok]
+    print(f"configs[1] walking, 1000 steps: |dp|/L = {dp.max() / extent:.2e}; {int((~ok).sum())} agents NaN on the "
+          f"reference's f64 path; walked {float((xy[ok, 0] - by_id[ok, 0]).mean()):.2f} m; CPU side {sec:.1f} s")
+    assert dp.max() / extent <= 1e-4
+    assert abs(float((a["x"] - by_id[:, 0]).mean()) - steps * 0.05 * scenes.WALK_SPEED) < 1e-2

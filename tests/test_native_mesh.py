@@ -266,3 +266,193 @@ def test_two_ranks_over_a_host_transport(tmp_path, kind, layout, port):
     probes = [(side * 0.5, side * 0.5), (side * 0.25, side * 0.6), (side * 0.75, side * 0.4)]
     assert near == single.query_radius_batch([6.0, 9.0, 4.0], probes)
     assert knn == single.query_knn_batch(5, probes)
+
+
+# ---- the domain's own edges on a mesh (review of round 3: only edges shared with a neighbour tile are strict) ----
+def _edge_scene(t):
+    """Walkers that leave the domain over its low-x and low-y edges (the reference bins them into row / column 0 and
+    keeps their exact position, location_hash_2d.rs:54-66), watched by Zanlungo neighbours that stay inside."""
+    lp = Zanlungo(1.0, 1.0, 0.0, 0.4, 2.0, 0.2)
+    t.add_agents([(0.5, 0.5), (0.7, 2.6), (0.6, 9.3)], StubHighLevelPlan((-0.4, 0.0)), NoLocalPlan(), 1.0)   # out over x = 0
+    t.add_agents([(7.5, 0.4), (10.6, 0.7)], StubHighLevelPlan((0.0, -0.4)), NoLocalPlan(), 1.0)              # out over y = 0
+    t.add_agents([(0.9, 0.8)], StubHighLevelPlan((-0.3, -0.3)), lp, 1.5)                                       # over the corner
+    t.add_agents([(1.4, 1.1), (1.2, 2.9), (8.1, 1.2), (1.6, 9.0)], StubHighLevelPlan((0.02, 0.01)), lp, 1.5)   # the watchers
+    t.add_agents([(-0.3, 4.2), (5.5, -0.2)], StubHighLevelPlan((0.0, 0.0)), lp, 1.5)   # added outside: clamped at once
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles", [(2, 2), (3, 1), (1, 3)])
+def test_domain_low_edges_clamp_on_a_mesh_like_the_reference(tiles):
+    grid = dict(width=12.0, height=12.0, cell_size=1.0, offset=(0.0, 0.0))
+    single, ora = Simulation(LocationHash2D(**grid)), OracleSimulation(LocationHash2D(**grid))
+    mesh = NativeTileMesh(LocationHash2D(**grid), tiles, 2)
+    local = LocalTileMesh(LocationHash2D(**grid), tiles, halo_cells=2)
+    for t in (single, ora, mesh, local):
+        _edge_scene(t)
+        for k in range(12):
+            t.step(0.5)
+    a, o = single.read_agents(), ora.read_agents()
+    assert (a["x"] < 0).sum() >= 5 and (a["y"] < 0).sum() >= 4   # they did leave
+    assert np.allclose(a["x"], o["x"], atol=2e-6) and np.allclose(a["y"], o["y"], atol=2e-6)
+    assert a.tobytes() == mesh.read_agents().tobytes() == local.read_agents().tobytes()
+    assert single.last_report["n_clamped"] == ora.last_report["n_clamped"] == mesh.last_report["n_clamped"] > 0
+    for probe, r in (((0.1, 0.5), 3.0), ((0.5, 3.0), 2.5), ((8.0, 0.2), 2.0)):
+        want = ora.get_neighbours_in_radius(r, probe)
+        assert single.get_neighbours_in_radius(r, probe) == want == mesh.get_neighbours_in_radius(r, probe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles", [(2, 2), (3, 1)])
+def test_nan_positioned_agents_on_a_mesh(tiles):
+    """location_to_index casts NaN to 0: such an agent sits in row / column 0 for ever and is inert; on a mesh the
+    tile that owns that cell holds it (tests/test_gpu_parity.py has the single-engine form)."""
+    def run(make):
+        sim = make()
+        lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+        ids = sim.add_agents([(1.0, 1.0), (float("nan"), 3.0), (1.6, 1.2), (float("nan"), float("nan")), (25.0, 30.0)],
+                             StubHighLevelPlan((0.1, 0.05)), lp, 2.0)
+        q = sim.get_neighbours_in_radius(3.0, (1.0, 1.0))
+        for _ in range(20):
+            sim.step(0.05)
+        return ids, q, sim.read_agents(), sim.last_report
+    grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
+    (ig, qg, ag, rg) = run(lambda: Simulation(LocationHash2D(**grid)))
+    (im, qm, am, rm) = run(lambda: NativeTileMesh(LocationHash2D(**grid), tiles, 1))
+    (io, qo, ao, ro) = run(lambda: OracleSimulation(LocationHash2D(**grid)))
+    assert ig == im == io and sorted(qg) == sorted(qm) == sorted(qo) == [0, 2]
+    assert len(am) == 5 and np.isnan(am["x"][1]) and np.isnan(am["y"][3])
+    # (NaN != NaN bytewise-equal still: same bit patterns from the same arithmetic)
+    assert ag.tobytes() == am.tobytes()
+    ok = [0, 2, 4]
+    assert np.allclose(am["x"][ok], ao["x"][ok], atol=1e-6) and np.allclose(am["y"][ok], ao["y"][ok], atol=1e-6)
+    assert rg["n_nonfinite"] == rm["n_nonfinite"] == ro["n_nonfinite"] == 2
+
+
+# ---- a step that fails on one tile stops the whole mesh (advisor, round 3) -------------------------------------
+def _runaway_scene(t):
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    t.add_agents([(10.0, 10.0), (30.0, 10.0), (10.0, 30.0), (30.0, 31.0), (20.0, 20.5)], StubHighLevelPlan((0.1, 0.0)), lp, 2.0)
+    return t.add_agents([(37.1, 30.0)], StubHighLevelPlan((4.0, 0.0)), NoLocalPlan(), 2.0)[0]   # leaves over x = 40 in the 15th step
+
+
+def _single_engine_failure_step():
+    single = Simulation(LocationHash2D(40.0, 40.0, 2.0, (0.0, 0.0)))
+    _runaway_scene(single)
+    for k in range(40):
+        try:
+            single.step(0.05, report=True)
+        except Exception as err:  # noqa: BLE001
+            assert "Index out of bounds" in str(err)
+            return k
+    raise AssertionError("the runaway never left")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_report", [True, False])
+def test_a_tile_whose_agent_leaves_the_grid_stops_the_whole_mesh(with_report):
+    """lib.rs:299-302: step returns Err("Index out of bounds").  The single engine commits nothing and can go on; a
+    mesh whose tile failed is stopped as a whole (the other tiles have taken the step): every later call reports the
+    same error, nothing is exchanged between tiles that stand at different time steps."""
+    grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
+    mesh = NativeTileMesh(LocationHash2D(**grid), (2, 2), 1)
+    _runaway_scene(mesh)
+    failed_at = _single_engine_failure_step()
+    assert failed_at == 14
+    raised = None
+    for k in range(60):
+        try:
+            mesh.step(0.05, report=with_report)
+            if not with_report and k % 8 == 7:
+                mesh.synchronize()
+        except Exception as err:  # noqa: BLE001
+            raised = (k, str(err))
+            break
+    assert raised is not None and "Index out of bounds" in raised[1]
+    assert raised[0] == failed_at if with_report else failed_at <= raised[0] <= failed_at + 8
+    for call in (lambda: mesh.step(0.05), lambda: mesh.read_agents(), lambda: mesh.add_agents([(5.0, 5.0)], StubHighLevelPlan((0, 0)), NoLocalPlan(), 1.0),
+                 lambda: mesh.synchronize(), lambda: mesh.recut()):
+        with pytest.raises(Exception, match="Index out of bounds"):
+            call()
+
+
+@pytest.mark.gpu
+def test_a_failing_step_of_the_distributed_form_is_agreed_on(monkeypatch):
+    """The distributed form over RCCL (here a communicator of one): steps made without a report do not wait for the
+    device, so the failure is acted on at the agreed check (every CS_MESH_CHECK_EVERY steps) or in synchronize, never by
+    leaving the schedule in the middle: until then the rank issues its steps' collectives and nothing else."""
+    monkeypatch.setenv("CS_MESH_CHECK_EVERY", "8")
+    grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
+    uid = Simulation(LocationHash2D(**grid)).rccl_unique_id()
+    mesh = NativeTileMesh(LocationHash2D(**grid), (1, 1), 1, rccl_unique_id=uid, rank=0, n_ranks=1)
+    _runaway_scene(mesh)
+    raised = None
+    for k in range(60):
+        try:
+            mesh.step(0.05, report=False)
+        except Exception as err:  # noqa: BLE001
+            raised = (k, str(err))
+            break
+    assert raised is not None and "Index out of bounds" in raised[1]
+    # at an agreed check, the first or second after the event (the single engine fails in step 14)
+    assert raised[0] in (15, 23) and raised[0] >= _single_engine_failure_step()
+    with pytest.raises(Exception, match="Index out of bounds"):
+        mesh.step(0.05, report=True)
+
+
+def _rank_failing(rank, world, port, out_path):
+    import os
+    import pickle
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rmf_crowdsim_amd.tiles import TorchHostTransport
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
+        mesh = NativeTileMesh(LocationHash2D(**grid), (2, 1), 1, device=0, rank=rank, n_ranks=world,
+                              host_transport=TorchHostTransport(dist))
+        _runaway_scene(mesh)   # the runaway lives on rank 1's tile (x >= 20)
+        raised = None
+        for k in range(60):
+            try:
+                mesh.step(0.05, report=False)
+            except Exception as err:  # noqa: BLE001
+                raised = (k, str(err))
+                break
+        again = None
+        try:
+            mesh.step(0.05, report=False)
+        except Exception as err:  # noqa: BLE001
+            again = str(err)
+        with open(f"{out_path}.{rank}", "wb") as f:
+            pickle.dump((raised, again), f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_agree_on_a_failure_and_nobody_hangs(tmp_path):
+    """One rank's tile fails; both ranks leave the schedule at the SAME step, the failing one with the reference's
+    error, the other with "a tile of this mesh failed ... on another rank"; nobody waits in an exchange for a peer
+    that has gone."""
+    import pickle
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "failing")
+    procs = [ctx.Process(target=_rank_failing, args=(r, 2, 29751, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung, "a rank was left waiting for a peer that had gone"
+    assert all(p.exitcode == 0 for p in procs)
+    got = [pickle.load(open(f"{out}.{r}", "rb")) for r in range(2)]
+    (r0, again0), (r1, again1) = got
+    assert r0 is not None and r1 is not None and r0[0] == r1[0] and 14 <= r0[0] <= 22
+    assert "Index out of bounds" in r1[1] and "another rank" in r0[1]
+    assert again0 == r0[1] and again1 == r1[1]

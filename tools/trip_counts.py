@@ -38,6 +38,25 @@ def main():
     print(f"  per wave: filter trips {d[5] / waves:.1f}  ttc trips {d[4] / waves:.1f} (entries per lane {d[7] / waves / 64:.1f})  "
           f"force trips {d[3] / waves:.1f} (entries per lane {d[6] / waves / 64:.1f})")
     print(f"  time-to-collision passes repeated in the guarded form: {d[8] / waves:.3f} per wave")
+    agents, finite = max(d[9], 1), d[10]
+    print(f"  agents on the LDS path per step {d[9] / steps:.0f}, with a finite time to collision {finite / agents:.4f}")
+    # the summary bench.py quotes per scene (bench.scene_stats; merged into profiles/rNN/scene_stats.json)
+    import json
+
+    class A:
+        cell, eyesight = 2.0, 2.0
+    key = bench.profile_key(f"scene {workload} agents {n} cell {A.cell} eyesight {A.eyesight}")
+    stats = {
+        "steps_counted": steps,
+        "mean_neighbours": d[7] / agents - 1.0,                 # listed entries per agent, the agent itself taken off
+        "finite_ttc_frac": finite / agents,                       # agents whose force pass runs (t_i != +inf)
+        "mean_forward_neighbours": d[6] / agents,                 # entries with the larger id (non-zero weight), per agent
+        "mean_forward_neighbours_of_finite": d[6] / max(finite, 1),
+        "filter_trips_per_wave": d[5] / waves, "ttc_trips_per_wave": d[4] / waves, "force_trips_per_wave": d[3] / waves,
+        "force_lane_use": (d[6] / waves / 64.0) / max(d[3] / waves, 1e-9),
+        "waves_beyond_lds_rows_frac": d[1] / waves,
+    }
+    print("SCENE_STATS " + json.dumps({key: {"workload": workload, "agents": n, **stats}}))
 
 
 if __name__ == "__main__":
