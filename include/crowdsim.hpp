@@ -146,7 +146,8 @@ struct LocalPlanner {
     return cs_register_lp_callback(
         e,
         [](void* u, size_t n, const cs_lp_agent* agents, const double* rec, const uint64_t* nb_begin,
-           const cs_lp_agent* nb, double* out) {
+           const cs_lp_agent* nb, double* out) -> int {
+          try {
           const auto view = [](const cs_lp_agent& r) {
             Agent a{};
             a.agent_id = r.agent_id;
@@ -164,6 +165,10 @@ struct LocalPlanner {
             out[2 * k] = v.x;
             out[2 * k + 1] = v.y;
           }
+          } catch (...) {  // (nothing may unwind through the C frame: the step fails instead)
+            return 1;
+          }
+          return 0;
         },
         this);
   }

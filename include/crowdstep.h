@@ -182,8 +182,10 @@ typedef struct cs_lp_agent {
   double eyesight_range;
   uint64_t next_waypoint;
 } cs_lp_agent;
-typedef void (*cs_lp_batch_fn)(void* user, size_t n_agents, const cs_lp_agent* agents, const double* recommended_xy,
-                               const uint64_t* nb_begin, const cs_lp_agent* neighbours, double* out_velocity_xy);
+/* Returns 0, or non-zero when the planner could not answer (an exception on the host's side, a poisoned lock): the step
+ * then fails with Err("a host LocalPlanner failed") and commits nothing, instead of integrating velocities nobody gave. */
+typedef int (*cs_lp_batch_fn)(void* user, size_t n_agents, const cs_lp_agent* agents, const double* recommended_xy,
+                              const uint64_t* nb_begin, const cs_lp_agent* neighbours, double* out_velocity_xy);
 
 /* struct SourceSink                              source_sink/source_sink.rs:36-60 */
 typedef struct cs_source_sink_desc {

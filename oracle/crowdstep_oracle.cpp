@@ -283,6 +283,7 @@ struct NoLocalPlan : LocalPlanner {
 struct CallbackLocalPlanner : LocalPlanner {
   cs_lp_batch_fn fn = nullptr;
   void* user = nullptr;
+  mutable bool failed = false;  // the callback returned non-zero in this step: the step reports it (cs_step)
   static cs_lp_agent record(const Agent& a, bool with_preferred) {
     cs_lp_agent r;
     r.agent_id = a.agent_id;
@@ -305,7 +306,7 @@ struct CallbackLocalPlanner : LocalPlanner {
     if (nb.empty()) nb.emplace_back();
     const double rec[2] = {(double)recommended.x, (double)recommended.y};
     double out[2] = {0.0, 0.0};
-    fn(user, 1, &me, rec, begin, nb.data(), out);
+    if (fn(user, 1, &me, rec, begin, nb.data(), out) != 0) failed = true;
     return V2{(Real)out[0], (Real)out[1]};
   }
 };
@@ -982,7 +983,14 @@ int cs_query_knn_batch(cs_engine* e, size_t n, const double* xy, size_t k, uint6
 }
 
 int cs_step(cs_engine* e, double dt_seconds, cs_step_report* report) {
-  const int rc = e->step(dt_seconds, report);
+  int rc = e->step(dt_seconds, report);
+  for (auto& lp : e->lps)
+    if (auto* cb = dynamic_cast<CallbackLocalPlanner*>(lp.get()))
+      if (cb->failed) {
+        cb->failed = false;
+        e->error = "a host LocalPlanner failed (its callback returned non-zero)";
+        rc = 9;
+      }
   if (rc == 0) e->steps_done += 1;
   return rc;
 }

@@ -66,7 +66,7 @@ class LpAgent(C.Structure):
                 ("eyesight_range", C.c_double), ("next_waypoint", C.c_uint64)]
 
 
-LpBatchFn = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.POINTER(LpAgent), C.POINTER(C.c_double),
+LpBatchFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(LpAgent), C.POINTER(C.c_double),
                         C.POINTER(C.c_uint64), C.POINTER(LpAgent), C.POINTER(C.c_double))
 
 

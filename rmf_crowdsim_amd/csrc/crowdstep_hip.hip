@@ -253,7 +253,9 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
     e->error = "unknown planner handle";
     return 2;
   }
-  if (int rc = e->room_for_group(0)) return rc;
+  // (a group this call only REUSES needs no room: asking first would widen the meta word, or refuse the call, for nothing)
+  if (e->plain_groups.find(std::make_tuple(hlp, lp, eyesight)) == e->plain_groups.end())
+    if (int rc = e->room_for_group(0)) return rc;
   uint32_t g = e->make_group(hlp, lp, eyesight, -1);
   return e->add_agents(xy, n, g, UINT32_MAX, out_ids);
 }
@@ -623,15 +625,19 @@ static int lp_callbacks_eval(cs_engine* e, const StepParams& P, const EpilogueCt
     }
     by_lp[g.lp].push_back(i);
   }
-  std::vector<uint32_t> slot_of_id;  // id -> slot + 1, for the neighbours' state
-  {
-    uint32_t max_id = 0;
-    for (uint32_t i = 0; i < n; ++i)
-      if (h.cell[i] != CS_INVALID_CELL) max_id = std::max(max_id, h.id[i]);
-    slot_of_id.assign((size_t)max_id + 1u, 0u);
-    for (uint32_t i = 0; i < n; ++i)
-      if (h.cell[i] != CS_INVALID_CELL) slot_of_id[h.id[i]] = i + 1u;
-  }
+  // id -> slot, for the neighbours' state: a sorted table of the live agents (ids grow without bound in a crowd fed
+  // by source-sinks: a table indexed by id would be as large as the largest id ever handed out)
+  std::vector<std::pair<uint32_t, uint32_t>> slot_of_id;
+  slot_of_id.reserve(n);
+  for (uint32_t i = 0; i < n; ++i)
+    if (h.cell[i] != CS_INVALID_CELL) slot_of_id.emplace_back(h.id[i], i);
+  std::sort(slot_of_id.begin(), slot_of_id.end());
+  auto find_slot = [&](uint32_t id, uint32_t* slot) {
+    const auto it = std::lower_bound(slot_of_id.begin(), slot_of_id.end(), std::make_pair(id, 0u));
+    if (it == slot_of_id.end() || it->first != id) return false;
+    *slot = it->second;
+    return true;
+  };
   auto agent_of = [&](uint32_t i, double pvx, double pvy) {
     cs_lp_agent a;
     a.agent_id = h.id[i];
@@ -675,14 +681,18 @@ static int lp_callbacks_eval(cs_engine* e, const StepParams& P, const EpilogueCt
     for (size_t k = 0; k < m; ++k) {
       for (uint32_t q = 0; q < counts[k]; ++q) {
         const uint32_t id = ids[k * cap + q];
-        if (id == agents[k].agent_id || id >= slot_of_id.size() || !slot_of_id[id]) continue;  // itself: lib.rs:284
-        neighbours.push_back(agent_of(slot_of_id[id] - 1u, 0.0, 0.0));
+        uint32_t slot = 0;
+        if (id == agents[k].agent_id || !find_slot(id, &slot)) continue;  // itself: lib.rs:284
+        neighbours.push_back(agent_of(slot, 0.0, 0.0));
       }
       nb_begin[k + 1] = neighbours.size();
     }
     if (neighbours.empty()) neighbours.emplace_back();  // (a valid pointer for an empty list)
-    e->lp_callbacks[lp].fn(e->lp_callbacks[lp].user, m, agents.data(), recommended.data(), nb_begin.data(),
-                           neighbours.data(), answer.data());
+    if (e->lp_callbacks[lp].fn(e->lp_callbacks[lp].user, m, agents.data(), recommended.data(), nb_begin.data(),
+                               neighbours.data(), answer.data()) != 0) {
+      e->error = "a host LocalPlanner failed (its callback returned non-zero): nothing was committed";
+      return 9;
+    }
     for (size_t k = 0; k < m; ++k) out[slots[k]] = make_float2((float)answer[2 * k], (float)answer[2 * k + 1]);
   }
   if (hipMemcpyAsync(e->lp_vel, out.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->stream) != hipSuccess ||

@@ -90,12 +90,17 @@ class LocalPlanner:
                           float(r.eyesight_range))
                 a.preferred_vel = preferred
                 return a
-            for k in range(n):
-                rec = np.array([recommended[2 * k], recommended[2 * k + 1]])
-                me = view(agents[k], rec)
-                nearby = [view(neighbours[q], np.zeros(2)) for q in range(nb_begin[k], nb_begin[k + 1])]
-                vx, vy = self.get_desired_velocity(me, nearby, rec)
-                out[2 * k], out[2 * k + 1] = float(vx), float(vy)
+            try:
+                for k in range(n):
+                    rec = np.array([recommended[2 * k], recommended[2 * k + 1]])
+                    me = view(agents[k], rec)
+                    nearby = [view(neighbours[q], np.zeros(2)) for q in range(nb_begin[k], nb_begin[k + 1])]
+                    vx, vy = self.get_desired_velocity(me, nearby, rec)
+                    out[2 * k], out[2 * k + 1] = float(vx), float(vy)
+            except Exception as err:  # noqa: BLE001 (an exception must not cross the C frame: the step fails instead)
+                self.failure = err
+                return 1
+            return 0
 
         fn = _abi.LpBatchFn(batch)
         # one thunk per engine this planner is registered with; the engines hold the raw pointer
@@ -407,7 +412,15 @@ class Simulation:
         return self._lib.cs_backend_name(self._engine).decode()
 
     def _err(self):
-        return CrowdSimError(self._lib.cs_last_error(self._engine).decode())
+        why = self._lib.cs_last_error(self._engine).decode()
+        for planner in self._planners_alive:  # a host planner that raised: its exception is the cause
+            cause = getattr(planner, "failure", None)
+            if cause is not None:
+                planner.failure = None
+                err = CrowdSimError(f"{why} ({cause!r})")
+                err.__cause__ = cause
+                return err
+        return CrowdSimError(why)
 
     def _handle(self, planner):
         key = id(planner)

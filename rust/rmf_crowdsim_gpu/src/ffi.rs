@@ -162,7 +162,7 @@ pub struct cs_lp_agent {
     pub eyesight_range: f64,
     pub next_waypoint: u64,
 }
-pub type cs_lp_batch_fn = Option<unsafe extern "C" fn(user: *mut c_void, n_agents: usize, agents: *const cs_lp_agent, recommended_xy: *const f64, nb_begin: *const u64, neighbours: *const cs_lp_agent, out_velocity_xy: *mut f64)>;
+pub type cs_lp_batch_fn = Option<unsafe extern "C" fn(user: *mut c_void, n_agents: usize, agents: *const cs_lp_agent, recommended_xy: *const f64, nb_begin: *const u64, neighbours: *const cs_lp_agent, out_velocity_xy: *mut f64) -> c_int>;
 
 /// HighLevelPlanner as data, highlevel_planners.rs:8-16
 #[repr(C)]

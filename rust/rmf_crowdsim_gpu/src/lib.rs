@@ -2,6 +2,11 @@
 // ffi.rs are checked mechanically against include/crowdstep.h (tools/check_ffi_layout.py); this
 // file is the host side a maintainer builds where `cargo` exists.
 //
+//
+// Attribution: the trait and struct declarations in this file restate, signature for signature, those of
+// open-rmf/rmf_crowdsim (Copyright (C) 2022 Open Source Robotics Foundation, licensed under the Apache License,
+// Version 2.0: http://www.apache.org/licenses/LICENSE-2.0), file rmf_crowdsim/src/lib.rs (EventListener, Agent, the type aliases and the public methods of Simulation); they are kept
+// identical on purpose, so that this crate drops in for that one.  Everything else in the file is original.
 //! `rmf_crowdsim`'s public surface over the MI355X crowd-step engine.
 //!
 //! Same items, names, argument order and error behaviour as the reference crate
@@ -20,8 +25,10 @@
 //! What differs, and why: trait objects cannot run on a GPU, so each trait gains ONE provided
 //! method (`device_form`) through which the planners the reference ships describe themselves as
 //! data; every other implementation keeps working through the documented slow paths
-//! (`HighLevelPlanner`: a batched host callback per step; `LocalPlanner`: refused with `Err`, as
-//! it would have to see every neighbour of every agent on the host).  The step is the canonical
+//! (`HighLevelPlanner`: a batched host callback per step; `LocalPlanner`: a batched host callback too,
+//! `cs_register_lp_callback`: the engine hands over every agent of the planner with its neighbours in
+//! canonical order, from the device's batch radius query, and takes the velocities back before it
+//! integrates).  The step is the canonical
 //! (Jacobi) member of the reference's order-dependent family: DESIGN.md section 2.
 
 pub extern crate nalgebra as na;
@@ -126,9 +133,13 @@ unsafe extern "C" fn hlp_velocity_trampoline(user: *mut c_void, n: usize, ids: *
 /// cs_lp_batch_fn: `LocalPlanner::get_desired_velocity` for every agent of one host planner (lib.rs:276-291)
 unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents: usize, agents: *const ffi::cs_lp_agent,
                                          recommended_xy: *const f64, nb_begin: *const u64,
-                                         neighbours: *const ffi::cs_lp_agent, out_velocity_xy: *mut f64) {
+                                         neighbours: *const ffi::cs_lp_agent, out_velocity_xy: *mut f64) -> std::os::raw::c_int {
     let planner = &*(user as *const Arc<Mutex<dyn LocalPlanner>>);
-    let p = planner.lock().unwrap();
+    // (a panic must not unwind through the C frame: a poisoned lock fails the step instead, with Err from `step`)
+    let p = match planner.lock() {
+        Ok(p) => p,
+        Err(_) => return 1,
+    };
     let view = |r: &ffi::cs_lp_agent| Agent {
         agent_id: r.agent_id as usize,
         position: Point::new(r.x, r.y),
@@ -146,6 +157,7 @@ unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents: usize, age
         *out_velocity_xy.add(2 * k) = v.x;
         *out_velocity_xy.add(2 * k + 1) = v.y;
     }
+    0
 }
 
 unsafe extern "C" fn hlp_set_target_trampoline(user: *mut c_void, id: u64, pos_x: f64, pos_y: f64, point_x: f64,

@@ -1,4 +1,9 @@
 // NEVER COMPILED (no Rust toolchain in the build image; see Cargo.toml).
+//
+// Attribution: the trait and struct declarations in this file restate, signature for signature, those of
+// open-rmf/rmf_crowdsim (Copyright (C) 2022 Open Source Robotics Foundation, licensed under the Apache License,
+// Version 2.0: http://www.apache.org/licenses/LICENSE-2.0), file rmf_crowdsim/src/spatial_index/{spatial_index,location_hash_2d}.rs; they are kept
+// identical on purpose, so that this crate drops in for that one.  Everything else in the file is original.
 use crate::ffi;
 use crate::{AgentId, Point};
 

@@ -315,7 +315,7 @@ def test_config4_four_million_agents_50_steps_with_a_recut():
           f"{after.max() / after.mean():.3f}")
     assert len(a) == n and (a["id"] == np.arange(n)).all() and a.tobytes() == b.tobytes()
     assert np.isfinite(a["x"]).all() and np.isfinite(a["vx"]).all()
-    assert after.sum() == n and after.max() / after.mean() < 1.2 < before.max() / before.mean()
+    assert after.sum() == n and after.max() / after.mean() < 1.05 < 1.12 < before.max() / before.mean()
     single.step(0.05)
     assert single.last_report["n_agents"] == n and single.last_report["n_nonfinite"] == 0
 

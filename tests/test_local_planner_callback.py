@@ -130,3 +130,32 @@ def test_a_custom_planner_gives_the_same_trajectory_on_engine_and_oracle(kernel)
     assert len(a) == len(b) >= 3000 and _err(a, b, extent) < 1e-6
     assert float(np.hypot(a["vx"] - b["vx"], a["vy"] - b["vy"]).max()) < 1e-5
     assert removed_a == removed_b and 7 in removed_a and len(removed_a) > 3   # the removal + agents that reached the sink
+
+
+class Raises(LocalPlanner):
+    def get_desired_velocity(self, agent, nearby_agents, recommended_velocity):
+        if agent.agent_id == 2:
+            raise ValueError("no answer for agent 2")
+        return recommended_velocity
+
+
+def _failing_planner(cls):
+    sim = cls(LocationHash2D(20.0, 20.0, 2.0, (0.0, 0.0)))
+    sim.add_agents([(1.0, 1.0), (3.0, 1.0), (5.0, 1.0)], StubHighLevelPlan((0.1, 0.0)), Raises(), 1.0)
+    with pytest.raises(Exception, match="host LocalPlanner failed") as info:
+        sim.step(0.05)
+    assert "no answer for agent 2" in str(info.value)   # the planner's own exception is named as the cause
+    return sim
+
+
+def test_a_host_planner_that_raises_fails_the_step_on_the_oracle():
+    """An exception inside the ctypes thunk used to be swallowed and the zero-initialised answers applied (the agents
+    silently stopped): the callback now reports failure and the step returns Err."""
+    _failing_planner(OracleSimulation)
+
+
+@pytest.mark.gpu
+def test_a_host_planner_that_raises_fails_the_step_on_the_engine():
+    sim = _failing_planner(Simulation)
+    a = sim.read_agents()
+    assert (a["x"] == [1.0, 3.0, 5.0]).all() and (a["vx"] == 0.0).all()   # nothing was committed
