@@ -339,6 +339,8 @@ def make_mesh(args, ctx, spatial_index, tiling, halo, density, capacity, flags, 
     import ctypes as C
     from rmf_crowdsim_amd import _abi, _native
     from rmf_crowdsim_amd.tiles import NativeTileMesh, TorchHostTransport
+    if os.environ.get("CS_BENCH_BREAK_NATIVE_MESH") == str(rank):  # (test hook: the fallback when ONE rank cannot set its tile up)
+        raise RuntimeError("native mesh creation failed on this rank (CS_BENCH_BREAK_NATIVE_MESH)")
     if backend == "nccl":
         # rank 0 makes the communicator's id, the launcher's process group hands it round; from then on every byte of
         # the step travels over RCCL from the engine (what a Rust host does with MPI or a file in torch's place)
@@ -478,10 +480,37 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         # add_agents call and keeps the agents of its own cells.  A rank that cannot set its tile up says where.
         mesh_kind = args.mesh
         arm(f"{leg_name}: mesh creation ({mesh_kind}; RCCL communicator init on the nccl backend)")
+        failure = None
         try:
             stepper, sim, how = make_mesh(args, ctx, LocationHash2D(**grid), tiling, halo, density, capacity, flags, weights)
-        except Exception as err:  # noqa: BLE001 (whatever it is, the rank must leave with the phase named)
-            fail(f"{leg_name}: mesh creation ({mesh_kind})", err)
+        except Exception as err:  # noqa: BLE001
+            failure = err
+        # Did every rank get its tile?  (Over the launcher's process group, which does not depend on the engine's own
+        # communicator.)  If the NATIVE mesh could not be set up somewhere, e.g. the engine could not bind librccl or
+        # ncclCommInitRank was refused, every rank drops it and the run goes on with the Python orchestration over
+        # torch.distributed's own point-to-point calls, saying so in the line: a scaling curve with a note beats none.
+        # Anything else a rank cannot recover from ends it with the phase named.
+        try:
+            bad = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        except Exception as err:  # noqa: BLE001 (the launcher's own process group does not work: nothing to fall back to)
+            fail(f"{leg_name}: mesh creation ({mesh_kind}): {failure}; and the process group's all-reduce", err)
+        if int(bad.item()):
+            if mesh_kind != "native" or os.environ.get("CS_BENCH_NO_FALLBACK"):
+                fail(f"{leg_name}: mesh creation ({mesh_kind})", failure or "another rank failed")
+            print(f"bench: rank {rank}: the native mesh could not be created ({failure or 'on another rank'}); falling back to "
+                  f"--mesh python over torch.distributed", file=sys.stderr, flush=True)
+            stepper = sim = None
+            os.environ["CS_TILES_TRANSPORT"] = "torch"
+            arm(f"{leg_name}: mesh creation (python, fallback)")
+            try:
+                fb = argparse.Namespace(**{**vars(args), "mesh": "python"})
+                stepper, sim, how = make_mesh(fb, ctx, LocationHash2D(**grid), tiling, halo, density, capacity, flags, weights)
+            except Exception as err:  # noqa: BLE001
+                fail(f"{leg_name}: mesh creation (python, fallback)", err)
+            mesh_kind = "python"
+            how["mesh"] = "python"
+            how["native_mesh_failed"] = str(failure or "on another rank")
         tile_report.update(how)
         if pts is not None:
             counts = TileCounts(LocationHash2D(**grid), tiling, weights, halo).of(pts)

@@ -95,6 +95,23 @@ def test_bench_gpus_2_python_mesh_for_comparison():
 
 
 @pytest.mark.gpu
+def test_a_native_mesh_that_cannot_be_created_falls_back_to_the_python_mesh_on_every_rank():
+    """One rank's cs_mesh_create fails (here: a test hook on rank 1; on a real node: librccl not bound, ncclCommInitRank
+    refused): the ranks agree over the launcher's process group, all drop the native mesh, and the run is measured on
+    the Python orchestration, saying so; with CS_BENCH_NO_FALLBACK the same failure ends the run with the phase named."""
+    common = [sys.executable, BENCH, "--gpus", "2", "--agents", "60000", "--steps", "5", "--warmup", "2", "--clock-warmup", "3",
+              "--no-cpu-baseline", "--no-second-scaling-leg"]
+    p = subprocess.run(common, env=_env(CS_BENCH_BACKEND="gloo", CS_BENCH_BREAK_NATIVE_MESH="1"), capture_output=True, text=True,
+                       timeout=900)
+    line = _bench_line(p)
+    assert line["config"]["mesh"] == "python" and "CS_BENCH_BREAK_NATIVE_MESH" in line["config"]["native_mesh_failed"]
+    assert line["value"] > 0 and "falling back" in p.stderr
+    p = subprocess.run(common, env=_env(CS_BENCH_BACKEND="gloo", CS_BENCH_BREAK_NATIVE_MESH="1", CS_BENCH_NO_FALLBACK="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0 and "FAILED in phase" in p.stderr and "mesh creation (native)" in p.stderr
+
+
+@pytest.mark.gpu
 def test_a_rank_that_cannot_set_up_its_transport_says_where_and_exits_non_zero():
     """RCCL refuses two ranks on one device; with the device check bypassed the native mesh's communicator init (or
     the first exchange) fails: every rank must leave with a non-zero code and the phase named, not hang."""
@@ -102,7 +119,7 @@ def test_a_rank_that_cannot_set_up_its_transport_says_where_and_exits_non_zero()
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a one-GPU box")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "20000", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--watchdog", "120"], env=_env(CS_BENCH_SHARE_DEVICE="1"),
+                        "--no-cpu-baseline", "--watchdog", "120"], env=_env(CS_BENCH_SHARE_DEVICE="1", CS_BENCH_NO_FALLBACK="1"),
                        capture_output=True, text=True, timeout=900)
     assert p.returncode != 0
     err = p.stderr + p.stdout
