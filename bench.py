@@ -339,7 +339,7 @@ def make_mesh(args, ctx, spatial_index, tiling, halo, density, capacity, flags, 
     import ctypes as C
     from rmf_crowdsim_amd import _abi, _native
     from rmf_crowdsim_amd.tiles import NativeTileMesh, TorchHostTransport
-    if os.environ.get("CS_BENCH_BREAK_NATIVE_MESH") == str(rank):  # (test hook: the fallback when ONE rank cannot set its tile up)
+    if os.environ.get("CS_BENCH_BREAK_NATIVE_MESH"):  # (test hook: the fallback when the ranks cannot set their tiles up)
         raise RuntimeError("native mesh creation failed on this rank (CS_BENCH_BREAK_NATIVE_MESH)")
     if backend == "nccl":
         # rank 0 makes the communicator's id, the launcher's process group hands it round; from then on every byte of
@@ -486,10 +486,11 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         except Exception as err:  # noqa: BLE001
             failure = err
         # Did every rank get its tile?  (Over the launcher's process group, which does not depend on the engine's own
-        # communicator.)  If the NATIVE mesh could not be set up somewhere, e.g. the engine could not bind librccl or
-        # ncclCommInitRank was refused, every rank drops it and the run goes on with the Python orchestration over
-        # torch.distributed's own point-to-point calls, saying so in the line: a scaling curve with a note beats none.
-        # Anything else a rank cannot recover from ends it with the phase named.
+        # communicator.)  If the NATIVE mesh could not be set up, e.g. the engine could not bind librccl or
+        # ncclCommInitRank was refused (failures every rank meets alike, before its first collective), every rank drops
+        # it and the run goes on with the Python orchestration over torch.distributed's own point-to-point calls, saying
+        # so in the line: a scaling curve with a note beats none.  (A failure on SOME ranks only leaves the others inside
+        # the creation's collectives: that is the watchdog's case.)  Anything else ends the rank with the phase named.
         try:
             bad = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)

@@ -96,8 +96,8 @@ def test_bench_gpus_2_python_mesh_for_comparison():
 
 @pytest.mark.gpu
 def test_a_native_mesh_that_cannot_be_created_falls_back_to_the_python_mesh_on_every_rank():
-    """One rank's cs_mesh_create fails (here: a test hook on rank 1; on a real node: librccl not bound, ncclCommInitRank
-    refused): the ranks agree over the launcher's process group, all drop the native mesh, and the run is measured on
+    """cs_mesh_create fails on the ranks (here: a test hook; on a real node: librccl not bound, ncclCommInitRank
+    refused): they agree over the launcher's process group, all drop the native mesh, and the run is measured on
     the Python orchestration, saying so; with CS_BENCH_NO_FALLBACK the same failure ends the run with the phase named."""
     common = [sys.executable, BENCH, "--gpus", "2", "--agents", "60000", "--steps", "5", "--warmup", "2", "--clock-warmup", "3",
               "--no-cpu-baseline", "--no-second-scaling-leg"]
