@@ -46,10 +46,21 @@ struct EventListener {  // lib.rs:22-33
   virtual void waypoint_reached(Vec2f, AgentId) {}
 };
 
-struct LocationHash2D {  // location_hash_2d.rs:33
+struct LocationHash2D;
+// trait SpatialIndex, spatial_index.rs:4-14: what Simulation<T: SpatialIndex> (lib.rs:69) is generic over.  On this
+// backend the index IS the neighbour kernel (the engine keeps the agents in a LocationHash2D's cell order and answers the
+// trait's four calls itself), so an index has to describe itself as such a grid: device_form() returns the LocationHash2D
+// it is equivalent to, or null, in which case Simulation's constructor throws.  No host-side slow path for a foreign
+// index exists (a per-agent host query per step would put the hot path on the CPU).
+struct SpatialIndex {
+  virtual ~SpatialIndex() = default;
+  virtual const LocationHash2D* device_form() const { return nullptr; }
+};
+struct LocationHash2D : SpatialIndex {  // location_hash_2d.rs:33
   double width, height, cell_size;
   Point offset;
   LocationHash2D(double w, double h, double cell, Point off) : width(w), height(h), cell_size(cell), offset(off) {}
+  const LocationHash2D* device_form() const override { return this; }
 };
 
 // highlevel_planners.rs:8-16.  Override get_desired_velocity for a host planner (batched
@@ -230,6 +241,15 @@ class Simulation {  // Simulation<LocationHash2D>, lib.rs:69-383
  public:
   std::unordered_map<AgentId, Agent> agents;  // lib.rs:71, refreshed after every mutating call
 
+  // Simulation<T: SpatialIndex>::new (lib.rs:103) for any index that describes itself as a grid
+  explicit Simulation(const SpatialIndex& any_index, int device = 0) : Simulation(as_grid(any_index), device) {}
+  static const LocationHash2D& as_grid(const SpatialIndex& index) {
+    const LocationHash2D* grid = index.device_form();
+    if (!grid)
+      throw std::runtime_error("Simulation<T: SpatialIndex>: on this backend the spatial index is the neighbour kernel itself; "
+                               "this index does not describe itself as a uniform grid (device_form() -> LocationHash2D)");
+    return *grid;
+  }
   explicit Simulation(const LocationHash2D& index, int device = 0) {  // lib.rs:103
     cs_grid_desc g{index.width, index.height, index.cell_size, index.offset.x, index.offset.y};
     cs_device_cfg cfg{};

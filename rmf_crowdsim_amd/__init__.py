@@ -7,14 +7,14 @@ from ._abi import (CS_CFG_DEFAULT, CS_CFG_DENSE, CS_CFG_FORCE_GATHER, CS_CFG_FOR
 from .simulation import (Agent, CrowdGenerator, CrowdSimError, EventListener, HighLevelPlanner,
                          IdParityHighLevelPlan, LocalPlanner, LocationHash2D, MonotonicCrowd,
                          NoHighLevelPlan, NoLocalPlan, RouteFollower, SeededPoissonCrowd, Simulation,
-                         SourceSink,
+                         SourceSink, SpatialIndex,
                          StubHighLevelPlan, Zanlungo)
 
 __all__ = [
     "Agent", "CrowdGenerator", "CrowdSimError", "EventListener", "HighLevelPlanner",
     "IdParityHighLevelPlan", "LocalPlanner", "LocationHash2D", "MonotonicCrowd",
     "NoHighLevelPlan", "NoLocalPlan", "RouteFollower", "SeededPoissonCrowd", "Simulation",
-    "SourceSink",
+    "SourceSink", "SpatialIndex",
     "StubHighLevelPlan", "Zanlungo", "CS_CFG_DEFAULT", "CS_CFG_DENSE", "CS_CFG_FORCE_GATHER",
     "CS_CFG_FORCE_TILED",
 ]

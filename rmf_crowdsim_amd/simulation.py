@@ -44,8 +44,38 @@ class Agent:
 
 
 # ---- spatial index ---------------------------------------------------------
-class LocationHash2D:
+class SpatialIndex:
+    """trait SpatialIndex, spatial_index.rs:4-14: what `Simulation<T: SpatialIndex>` (lib.rs:69) is generic over.
+
+    On this backend the index IS the neighbour kernel: the engine keeps the agents in the cell order of a
+    `LocationHash2D` and answers `get_neighbours_in_radius` / `get_nearest_neighbours` / `add_or_update` /
+    `remove_agent` itself (`Simulation.get_neighbours_in_radius`, `.get_nearest_neighbours`, the step's re-binning,
+    `.remove_agents`).  An index therefore has to describe itself as such a grid: `device_form()` returns the
+    `LocationHash2D` it is equivalent to (the one provided method this mirror adds to the trait, like the planners'), or
+    None, in which case `Simulation(index)` refuses it with an error that says so.  There is no host-side slow path
+    for a foreign index (unlike the planners: a per-agent host query per step would put the hot path on the CPU)."""
+
+    def add_or_update(self, index, position):           # spatial_index.rs:6
+        raise NotImplementedError
+
+    def get_nearest_neighbours(self, n, position):       # spatial_index.rs:8
+        raise NotImplementedError
+
+    def get_neighbours_in_radius(self, radius, position):  # spatial_index.rs:10
+        raise NotImplementedError
+
+    def remove_agent(self, index):                       # spatial_index.rs:12
+        raise NotImplementedError
+
+    def device_form(self):
+        return None
+
+
+class LocationHash2D(SpatialIndex):
     """LocationHash2D::new(width, height, cell_size, offset); location_hash_2d.rs:33."""
+
+    def device_form(self):
+        return self
 
     def __init__(self, width, height, cell_size, offset):
         self.width = float(width)
@@ -356,6 +386,12 @@ class Simulation:
     def __init__(self, spatial_index, device=0, flags=_abi.CS_CFG_DEFAULT, capacity_hint=0,
                  stream=None, tile=None, halo_cells=0):
         self._lib = self._load_library()
+        form = spatial_index.device_form() if hasattr(spatial_index, "device_form") else None
+        if form is None or not hasattr(form, "_desc"):
+            raise CrowdSimError(
+                "Simulation<T: SpatialIndex>: on this backend the spatial index is the neighbour kernel itself; "
+                f"{type(spatial_index).__name__} does not describe itself as a uniform grid (device_form() -> LocationHash2D)")
+        spatial_index = form
         grid = spatial_index._desc()
         cfg = _abi.DeviceCfg(int(device), int(flags), 0, 0, 0, 0, 0, 0, int(capacity_hint),
                              C.c_void_p(stream) if stream else None)

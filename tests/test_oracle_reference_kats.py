@@ -390,3 +390,26 @@ def test_walking_scene_is_certified_on_the_oracle():
     start = np.empty_like(pts)
     start[ids] = pts
     assert np.allclose(a["x"] - start[:, 0], 65.0, atol=1e-9)
+
+
+def test_a_foreign_spatial_index_is_refused_with_a_reason():
+    """Simulation<T: SpatialIndex> (lib.rs:69; spatial_index.rs:4-14): the mirror has the trait; an index that wraps a
+    LocationHash2D is accepted through device_form(), one that does not describe itself as a grid is refused."""
+    from rmf_crowdsim_amd import SpatialIndex
+
+    class Wrapped(SpatialIndex):
+        def __init__(self):
+            self.grid = LocationHash2D(20.0, 20.0, 2.0, (0.0, 0.0))
+
+        def device_form(self):
+            return self.grid
+
+    class Foreign(SpatialIndex):
+        pass
+
+    sim = OracleSimulation(Wrapped())
+    sim.add_agents([(1.0, 1.0)], StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(), 1.0)
+    sim.step(1.0)
+    assert sim.agents[0].position[0] == pytest.approx(2.0)
+    with pytest.raises(Exception, match="does not describe itself as a uniform grid"):
+        OracleSimulation(Foreign())
