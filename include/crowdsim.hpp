@@ -153,11 +153,8 @@ struct LocalPlanner {
     (void)agent; (void)nearby_agents;
     return recommended_velocity;
   }
-  virtual uint32_t register_with(cs_engine* e) {
-    return cs_register_lp_callback(
-        e,
-        [](void* u, size_t n, const cs_lp_agent* agents, const double* rec, const uint64_t* nb_begin,
-           const cs_lp_agent* nb, double* out) -> int {
+  static int batch_thunk(void* u, size_t n, const cs_lp_agent* agents, const double* rec, const uint64_t* nb_begin,
+                         const cs_lp_agent* nb, double* out) {
           try {
           const auto view = [](const cs_lp_agent& r) {
             Agent a{};
@@ -180,13 +177,10 @@ struct LocalPlanner {
             return 1;
           }
           return 0;
-        },
-        this);
   }
-  // (a tile mesh evaluates planners on every tile: the device planners register as data, host code does not)
-  virtual uint32_t register_with(cs_mesh*) {
-    throw std::runtime_error("a host LocalPlanner runs on a single engine (Simulation), not on a tile mesh");
-  }
+  virtual uint32_t register_with(cs_engine* e) { return cs_register_lp_callback(e, &LocalPlanner::batch_thunk, this); }
+  // (a tile mesh evaluates planners on every tile: each tile asks for the agents it owns)
+  virtual uint32_t register_with(cs_mesh* m) { return cs_mesh_register_lp_callback(m, &LocalPlanner::batch_thunk, this); }
 };
 struct NoLocalPlan : LocalPlanner {  // no_local_plan.rs:7-18
   uint32_t register_with(cs_engine* e) override { return cs_register_no_local_plan(e); }

@@ -565,6 +565,10 @@ int cs_mesh_tile_rect(const cs_mesh*, size_t local_index, uint32_t* rect4 /* cx0
 uint32_t cs_mesh_register_zanlungo(cs_mesh*, const cs_zanlungo_params*);
 uint32_t cs_mesh_register_no_local_plan(cs_mesh*);
 uint32_t cs_mesh_register_hlp(cs_mesh*, const cs_hlp_desc*);
+/* a LocalPlanner that is host code (local_planner.rs:7-18; cs_register_lp_callback): every tile asks it for the agents
+ * it owns, with their neighbours (ghosts of the tile included) in canonical order; such a mesh steps through the host
+ * every step, like one with listeners */
+uint32_t cs_mesh_register_lp_callback(cs_mesh*, cs_lp_batch_fn fn, void* user);
 int cs_mesh_add_agents(cs_mesh*, const double* xy, size_t n, uint32_t hlp, uint32_t lp, double eyesight,
                        uint64_t* out_ids);                                        /* lib.rs:119-156 */
 uint32_t cs_mesh_add_source_sink(cs_mesh*, const cs_source_sink_desc*);           /* lib.rs:159 */

@@ -1194,6 +1194,7 @@ int cs_mesh_tile_rect(const cs_mesh* m, size_t k, uint32_t* r) {
 uint32_t cs_mesh_register_zanlungo(cs_mesh* m, const cs_zanlungo_params* p) { return cs_register_zanlungo(m->e, p); }
 uint32_t cs_mesh_register_no_local_plan(cs_mesh* m) { return cs_register_no_local_plan(m->e); }
 uint32_t cs_mesh_register_hlp(cs_mesh* m, const cs_hlp_desc* d) { return cs_register_hlp(m->e, d); }
+uint32_t cs_mesh_register_lp_callback(cs_mesh* m, cs_lp_batch_fn fn, void* user) { return cs_register_lp_callback(m->e, fn, user); }
 int cs_mesh_add_agents(cs_mesh* m, const double* xy, size_t n, uint32_t hlp, uint32_t lp, double eyesight, uint64_t* out) {
   return cs_add_agents(m->e, xy, n, hlp, lp, eyesight, out);
 }

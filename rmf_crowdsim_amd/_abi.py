@@ -220,6 +220,7 @@ SYMBOLS = {
     "cs_mesh_register_zanlungo": (C.c_uint32, [C.c_void_p, C.POINTER(ZanlungoParams)]),
     "cs_mesh_register_no_local_plan": (C.c_uint32, [C.c_void_p]),
     "cs_mesh_register_hlp": (C.c_uint32, [C.c_void_p, C.POINTER(HlpDesc)]),
+    "cs_mesh_register_lp_callback": (C.c_uint32, [C.c_void_p, LpBatchFn, C.c_void_p]),
     "cs_mesh_add_agents": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_uint32, C.c_uint32,
                                       C.c_double, C.POINTER(C.c_uint64)]),
     "cs_mesh_add_source_sink": (C.c_uint32, [C.c_void_p, C.POINTER(SourceSinkDesc)]),

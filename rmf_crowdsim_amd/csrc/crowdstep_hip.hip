@@ -94,7 +94,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev); hipFree(e->query_scratch);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -552,13 +552,28 @@ static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const do
     Q.r = (float)r;
     Q.pad = 0;
   }
-  QueryDev* d_q = nullptr;
-  uint32_t *d_ids = nullptr, *d_cells = nullptr, *d_cnt = nullptr;
-  float* d_d2 = nullptr;
-  bool ok = hipMalloc(&d_q, n * sizeof(QueryDev)) == hipSuccess && hipMalloc(&d_ids, n * cap * sizeof(uint32_t)) == hipSuccess &&
-            hipMalloc(&d_d2, n * cap * sizeof(float)) == hipSuccess && hipMalloc(&d_cells, n * cap * sizeof(uint32_t)) == hipSuccess &&
-            hipMalloc(&d_cnt, n * sizeof(uint32_t)) == hipSuccess;
+  // device scratch of the batch, kept on the engine and grown as needed (a host local planner asks a batch per planner
+  // and step: five hipMalloc / hipFree pairs per call used to cost more than the query itself)
+  auto up = [](size_t b) { return (b + 255u) & ~(size_t)255u; };
+  const size_t o_ids = up(n * sizeof(QueryDev)), o_d2 = o_ids + up(n * cap * sizeof(uint32_t)),
+               o_cells = o_d2 + up(n * cap * sizeof(float)), o_cnt = o_cells + up(n * cap * sizeof(uint32_t)),
+               total = o_cnt + up(n * sizeof(uint32_t));
+  bool ok = true;
+  if (total > e->query_scratch_bytes) {
+    hipStreamSynchronize(e->stream);
+    hipFree(e->query_scratch);
+    e->query_scratch = nullptr;
+    e->query_scratch_bytes = 0;
+    ok = hipMalloc(&e->query_scratch, total + total / 4) == hipSuccess;
+    if (ok) e->query_scratch_bytes = total + total / 4;
+  }
   if (ok) {
+    unsigned char* base = static_cast<unsigned char*>(e->query_scratch);
+    QueryDev* d_q = reinterpret_cast<QueryDev*>(base);
+    uint32_t* d_ids = reinterpret_cast<uint32_t*>(base + o_ids);
+    float* d_d2 = reinterpret_cast<float*>(base + o_d2);
+    uint32_t* d_cells = reinterpret_cast<uint32_t*>(base + o_cells);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + o_cnt);
     ok = hipMemcpyAsync(d_q, q.data(), n * sizeof(QueryDev), hipMemcpyHostToDevice, e->stream) == hipSuccess;
     hipLaunchKernelGGL(k_query_radius_batch, dim3((uint32_t)n), dim3(64), 0, e->stream, e->gdev, e->buf[e->cur],
                        e->cell_start, d_q, (uint32_t)n, (uint32_t)e->gnx, (e->tile && e->ghosts_present && !with_ghosts) ? 1u : 0u, d_ids,
@@ -569,7 +584,6 @@ static int radius_query_batch(cs_engine* e, size_t n, const double* xy, const do
          hipMemcpyAsync(cells->data(), d_cells, n * cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
          hipStreamSynchronize(e->stream) == hipSuccess;
   }
-  hipFree(d_q); hipFree(d_ids); hipFree(d_d2); hipFree(d_cells); hipFree(d_cnt);
   if (!ok) {
     e->error = "HIP error in a batch of spatial queries";
     return 90;

@@ -395,7 +395,7 @@ class _MeshRegistrar:
             return getattr(self._lib, "cs_mesh_register_" + name[len("cs_register_"):])
         if name == "cs_last_error":
             return self._lib.cs_mesh_last_error
-        raise AttributeError(f"{name}: not available on a mesh (host local planners go through single engines)")
+        raise AttributeError(f"{name}: not available on a mesh")
 
 
 class TorchHostTransport:
@@ -493,6 +493,7 @@ class NativeTileMesh:
             raise CrowdSimError("cs_mesh_create failed: " + self._lib.cs_mesh_last_error(None).decode())
         self._registrar = _MeshRegistrar(self._lib)
         self._handles, self._alive, self._listeners = {}, [], []
+        self._host_lp_of_agent, self._host_lp_of_sink = {}, {}  # LocalPlanner::remove_agent follows the destroy events
         self.last_report = None
         self.shape = (desc.tiles_x, desc.tiles_y)
 
@@ -504,6 +505,9 @@ class NativeTileMesh:
     def _err(self):
         why = self._lib.cs_mesh_last_error(self._mesh).decode()
         cause = getattr(self._host_transport, "failure", None)
+        for planner in self._alive:  # a host planner that raised: its exception is the cause
+            if cause is None and getattr(planner, "failure", None) is not None:
+                cause, planner.failure = planner.failure, None
         return self._err_cls(why + (f" ({cause!r})" if cause is not None else ""))
 
     def _handle(self, planner):
@@ -517,12 +521,18 @@ class NativeTileMesh:
         return self._handles[key]
 
     def _dispatch(self):
-        if not self._listeners:
+        if not self._listeners and not self._host_lp_of_agent and not self._host_lp_of_sink:
             return
         buf = (_abi.Event * 4096)()
         while True:
             n = self._lib.cs_mesh_drain_events(self._mesh, buf, len(buf))
             for i in range(n):
+                if buf[i].kind == _abi.CS_EVENT_SPAWNED and buf[i].source_sink in self._host_lp_of_sink:
+                    self._host_lp_of_agent[int(buf[i].id)] = self._host_lp_of_sink[buf[i].source_sink]
+                elif buf[i].kind == _abi.CS_EVENT_DESTROYED:
+                    planner = self._host_lp_of_agent.pop(int(buf[i].id), None)
+                    if planner is not None:
+                        planner.remove_agent(int(buf[i].id))   # local_planner.rs:16 via lib.rs:181-184
                 for listener in self._listeners:
                     if buf[i].kind == _abi.CS_EVENT_SPAWNED:
                         listener.agent_spawned(np.array([buf[i].x, buf[i].y]), int(buf[i].id))
@@ -538,6 +548,10 @@ class NativeTileMesh:
         rc = self._lib.cs_mesh_add_agents(self._mesh, pts.ctypes.data_as(C.POINTER(C.c_double)), len(pts),
                                           self._handle(high_level_planner), self._handle(local_planner), float(eyesight),
                                           ids.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if getattr(local_planner, "_host_code", False) and rc == 0:
+            self._lib.cs_mesh_event_recording(self._mesh, 1)
+            for i in ids:
+                self._host_lp_of_agent[int(i)] = local_planner
         self._dispatch()
         if rc != 0:
             raise self._err()
@@ -550,6 +564,9 @@ class NativeTileMesh:
         if handle == 0xFFFFFFFF:
             raise self._err()
         self._alive.append((source_sink, keep))
+        if getattr(source_sink.local_planner, "_host_code", False):
+            self._host_lp_of_sink[handle] = source_sink.local_planner
+            self._lib.cs_mesh_event_recording(self._mesh, 1)
         return handle
 
     def remove_source_sink(self, handle):
@@ -567,7 +584,7 @@ class NativeTileMesh:
 
     def step(self, dur, report=True):
         rep = _abi.StepReport()
-        need = report or bool(self._listeners)
+        need = report or bool(self._listeners) or bool(self._host_lp_of_agent) or bool(self._host_lp_of_sink)
         rc = self._lib.cs_mesh_step(self._mesh, float(dur), self._C.byref(rep) if need else None)
         if need:
             self.last_report = rep.as_dict()

@@ -325,6 +325,7 @@ extern "C" {
     pub fn cs_mesh_register_zanlungo(m: *mut cs_mesh, p: *const cs_zanlungo_params) -> u32;
     pub fn cs_mesh_register_no_local_plan(m: *mut cs_mesh) -> u32;
     pub fn cs_mesh_register_hlp(m: *mut cs_mesh, d: *const cs_hlp_desc) -> u32;
+    pub fn cs_mesh_register_lp_callback(m: *mut cs_mesh, f: cs_lp_batch_fn, user: *mut c_void) -> u32;
     pub fn cs_mesh_add_agents(m: *mut cs_mesh, xy: *const f64, n: usize, hlp: u32, lp: u32, eyesight: f64, out_ids: *mut u64) -> c_int;
     pub fn cs_mesh_add_source_sink(m: *mut cs_mesh, d: *const cs_source_sink_desc) -> u32;
     pub fn cs_mesh_remove_source_sink(m: *mut cs_mesh, handle: u32);

@@ -159,3 +159,49 @@ def test_a_host_planner_that_raises_fails_the_step_on_the_engine():
     sim = _failing_planner(Simulation)
     a = sim.read_agents()
     assert (a["x"] == [1.0, 3.0, 5.0]).all() and (a["vx"] == 0.0).all()   # nothing was committed
+
+
+def _mesh_scene(target, lp):
+    pts = scenes.jittered_lattice(3000, 0.63, (10.0, 10.0), 0.2, 5)   # 2.5 agents / m^2 on [10, 45)^2: all four tiles of a 2 x 2 mesh
+    ids = target.add_agents(pts[:2000], IdParityHighLevelPlan((0.0, 0.05)), lp, 1.5)
+    target.add_agents(pts[2000:], StubHighLevelPlan((0.03, 0.0)), Zanlungo(*PARAMS), 2.0)
+    target.add_source_sink(SourceSink((60.0, 60.0), 0.5, MonotonicCrowd(20.0), StubHighLevelPlan((2.0, 0.0)), lp,
+                                      [(60.6, 60.0)], False, 1.5))
+    return ids
+
+
+def test_a_host_planner_on_the_oracles_mesh_binding():
+    """cs_mesh_register_lp_callback through NativeTileMesh on the oracle's one-process "mesh" (CPU plumbing)."""
+    from oracle_sim import load_oracle
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+    grid = dict(width=80.0, height=80.0, cell_size=2.0, offset=(0.0, 0.0))
+    out = []
+    for make in (lambda: OracleSimulation(LocationHash2D(**grid)),
+                 lambda: NativeTileMesh(LocationHash2D(**grid), (2, 2), 1, library=load_oracle("f64"))):
+        t, lp = make(), Nonsense()
+        _mesh_scene(t, lp)
+        for k in range(6):
+            t.step(0.05)
+        out.append((t.read_agents(), lp.removed))
+    assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1] == out[1][1] and len(out[0][1]) > 0
+
+
+@pytest.mark.gpu
+def test_a_host_planner_on_a_tile_mesh_equals_the_single_engine():
+    """A `LocalPlanner` in host code on a 2 x 2 mesh (round 4: cs_mesh_register_lp_callback): every tile asks the planner
+    for the agents it owns, with ghosts among the neighbours, in canonical order; agents cross the cuts; a source-sink
+    of the host planner spawns and destroys (remove_agent reaches the planner).  Same bits as one engine."""
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+    grid = dict(width=80.0, height=80.0, cell_size=2.0, offset=(0.0, 0.0))
+    out = []
+    for make in (lambda: Simulation(LocationHash2D(**grid)), lambda: NativeTileMesh(LocationHash2D(**grid), (2, 2), 1)):
+        t, lp = make(), Nonsense()
+        ids = _mesh_scene(t, lp)
+        for k in range(25):
+            t.step(0.05)
+            if k == 10:
+                t.remove_agents(ids[7])
+        out.append((t.read_agents(), sorted(lp.removed)))
+    (a, removed_a), (b, removed_b) = out
+    assert len(a) >= 3000 and a.tobytes() == b.tobytes()
+    assert removed_a == removed_b and 7 in removed_a and len(removed_a) > 3
