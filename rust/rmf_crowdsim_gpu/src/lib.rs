@@ -131,7 +131,7 @@ unsafe extern "C" fn hlp_velocity_trampoline(user: *mut c_void, n: usize, ids: *
 }
 
 /// cs_lp_batch_fn: `LocalPlanner::get_desired_velocity` for every agent of one host planner (lib.rs:276-291)
-unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents: usize, agents: *const ffi::cs_lp_agent,
+pub(crate) unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents: usize, agents: *const ffi::cs_lp_agent,
                                          recommended_xy: *const f64, nb_begin: *const u64,
                                          neighbours: *const ffi::cs_lp_agent, out_velocity_xy: *mut f64) -> std::os::raw::c_int {
     let planner = &*(user as *const Arc<Mutex<dyn LocalPlanner>>);

@@ -7,6 +7,7 @@
 // `Simulation` (one engine).
 use std::collections::HashMap;
 use std::ffi::CStr;
+use std::os::raw::c_void;
 use std::sync::{Arc, Mutex};
 
 use crate::ffi;
@@ -35,6 +36,7 @@ pub struct TiledSimulation {
     mesh: *mut ffi::cs_mesh,
     hlp_handles: HashMap<usize, u32>,
     lp_handles: HashMap<usize, u32>,
+    keep_lps: Vec<Box<Arc<Mutex<dyn LocalPlanner>>>>,  // what the mesh's `user` pointers of host planners point at
     listeners: Vec<Arc<Mutex<dyn EventListener>>>,
     keep_sinks: Vec<Arc<SourceSink>>,
 }
@@ -84,6 +86,7 @@ impl TiledSimulation {
             mesh,
             hlp_handles: HashMap::new(),
             lp_handles: HashMap::new(),
+            keep_lps: Vec::new(),
             listeners: Vec::new(),
             keep_sinks: Vec::new(),
         })
@@ -141,7 +144,14 @@ impl TiledSimulation {
         let handle = match planner.lock().unwrap().device_form() {
             DeviceLocalPlan::NoLocalPlan => unsafe { ffi::cs_mesh_register_no_local_plan(self.mesh) },
             DeviceLocalPlan::Zanlungo(params) => unsafe { ffi::cs_mesh_register_zanlungo(self.mesh, &params) },
-            DeviceLocalPlan::HostCallback => return Err("a host LocalPlanner runs on a single engine (Simulation), not on a tile mesh".to_string()),
+            DeviceLocalPlan::HostCallback => {
+                // every tile asks the planner for the agents it owns (cs_mesh_register_lp_callback); the mesh keeps
+                // `user`: a heap cell holding a clone of the Arc, alive as long as `self`
+                let cell = Box::new(planner.clone());
+                let user = &*cell as *const Arc<Mutex<dyn LocalPlanner>> as *mut c_void;
+                self.keep_lps.push(cell);
+                unsafe { ffi::cs_mesh_register_lp_callback(self.mesh, Some(crate::lp_batch_trampoline), user) }
+            }
         };
         if handle == u32::MAX {
             return Err(self.last_error());
