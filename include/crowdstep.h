@@ -350,6 +350,9 @@ uint64_t cs_device_bytes(cs_engine*);
  * by a change of the agents in between) */
 #define CS_STAT_EXCHANGES_AHEAD 2u
 #define CS_STAT_EXCHANGES_AHEAD_USED 3u
+/* steps of a small crowd that ran on the band windows of an earlier step (the window builder runs every 4th step there:
+ * windows built to tile their band completely, with room to spare, stay correct while the agents move) */
+#define CS_STAT_STEPS_ON_KEPT_WINDOWS 4u
 uint64_t cs_kernel_stat(cs_engine*, uint32_t which);
 
 /* ---- measurement (bench.py / rocprof cross-check) ---------------------- */

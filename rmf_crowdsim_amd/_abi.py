@@ -16,6 +16,7 @@ CS_STAT_WINDOWS_OFF_LDS = 0
 CS_STAT_WINDOWS_CHUNKED = 1
 CS_STAT_EXCHANGES_AHEAD = 2
 CS_STAT_EXCHANGES_AHEAD_USED = 3
+CS_STAT_STEPS_ON_KEPT_WINDOWS = 4
 
 CS_HLP_NONE, CS_HLP_CONSTANT, CS_HLP_ID_PARITY, CS_HLP_CALLBACK, CS_HLP_ROUTE = 0, 1, 2, 3, 4
 CS_ROUTE_MAX_WAYPOINTS = 1023

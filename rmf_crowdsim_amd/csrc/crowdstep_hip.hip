@@ -94,7 +94,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->n_blocks_dev); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev); hipFree(e->query_scratch);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->blk_desc_back); hipFree(e->n_blocks_dev); hipFree(e->n_blocks_back); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev); hipFree(e->query_scratch);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -158,15 +158,24 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, e->device);
   e->backend = std::string("hip:") + prop.gcnArchName;
-  for (const void* fn : {reinterpret_cast<const void*>(k_step_tiled<false>), reinterpret_cast<const void*>(k_step_tiled<true>)}) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-      (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
-    // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes)
-      e->tile_static_lds = std::max(e->tile_static_lds == 512u ? 0u : e->tile_static_lds, (uint32_t)fa.sharedSizeBytes);
-    (void)hipGetLastError();
+  {
+    const void* kernels[4] = {reinterpret_cast<const void*>(k_step_tiled<false, false>), reinterpret_cast<const void*>(k_step_tiled<true, false>),
+                              reinterpret_cast<const void*>(k_step_tiled<false, true>), reinterpret_cast<const void*>(k_step_tiled<true, true>)};
+    for (int k = 0; k < 4; ++k) {
+      if (hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
+      // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB (the instantiations with builder
+      // workgroups, k >= 2, carry the window builder's small arrays as well: priced for themselves)
+      hipFuncAttributes fa;
+      uint32_t& slot = k < 2 ? e->tile_static_lds : e->tile_static_lds_builders;
+      if (hipFuncGetAttributes(&fa, kernels[k]) == hipSuccess && fa.sharedSizeBytes)
+        slot = std::max(slot == 512u ? 0u : slot, (uint32_t)fa.sharedSizeBytes);
+      (void)hipGetLastError();
+    }
   }
+  if (const char* v = getenv("CS_WINDOWS_KEEP")) e->windows_shadow = atoi(v) != 0;  // 0: the window builder in every step's own launch
+  if (const char* v = getenv("CS_WINDOWS_SLACK")) e->windows_slack_pct = (uint32_t)std::max(0, atoi(v));  // room in a kept window, percent
+  if (const char* v = getenv("CS_WINDOWS_KEEP_MAX_AGENTS")) e->windows_keep_max_agents = (uint32_t)std::max(0, atoi(v));
   if (const char* v = getenv("CS_TILE_BLOCKS_PER_CU")) e->tile_blocks_per_cu = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_MIN_ROWS")) e->tile_min_rows = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_LIST_CAP")) e->tile_list_cap = (uint32_t)atoi(v);
@@ -310,6 +319,7 @@ uint64_t cs_kernel_stat(cs_engine* e, uint32_t which) {
   hipSetDevice(e->device);
   if (which == CS_STAT_EXCHANGES_AHEAD) return e->n_exchanges_ahead;
   if (which == CS_STAT_EXCHANGES_AHEAD_USED) return e->n_exchanges_ahead_used;
+  if (which == CS_STAT_STEPS_ON_KEPT_WINDOWS) return e->n_steps_on_kept_windows;
   Counters c;
   if (e->read_counters(&c)) return 0;
   switch (which) {

@@ -22,6 +22,7 @@ pub const CS_STAT_WINDOWS_OFF_LDS: u32 = 0;
 pub const CS_STAT_WINDOWS_CHUNKED: u32 = 1;
 pub const CS_STAT_EXCHANGES_AHEAD: u32 = 2;
 pub const CS_STAT_EXCHANGES_AHEAD_USED: u32 = 3;
+pub const CS_STAT_STEPS_ON_KEPT_WINDOWS: u32 = 4;
 
 pub const CS_HLP_NONE: u32 = 0;
 pub const CS_HLP_CONSTANT: u32 = 1;
