@@ -186,6 +186,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_WINDOWS_CAP")) e->tile_windows_cap = (uint32_t)atoi(v);
+  if (const char* v = getenv("CS_CHECK_WINDOWS")) e->check_windows = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
   const bool is_tile = cfg && (cfg->tile_cx1 | cfg->tile_cy1);

@@ -92,9 +92,10 @@ int main() {
   sd.agent_eyesight_range = 2.0;
   CHECK(cs_mesh_add_source_sink(mesh, &sd) == cs_add_source_sink(one, &sd));
 
-  auto same = [&]() {
-    const size_t n = cs_agent_count(one);
-    CHECK(cs_mesh_agent_count(mesh) == n);
+  auto same = [&](const char* when) {
+    const size_t n = cs_agent_count(one), n_mesh = cs_mesh_agent_count(mesh);
+    if (n_mesh != n) std::printf("%s: %zu agents on the mesh, %zu on the engine (%s | %s)\n", when, n_mesh, n, cs_mesh_last_error(mesh), cs_last_error(one));
+    CHECK(n_mesh == n);
     std::vector<cs_agent_view> a(n), b(n);
     CHECK(cs_read_agents(one, a.data(), n) == n && cs_mesh_read_agents(mesh, b.data(), n) == n);
     CHECK(std::memcmp(a.data(), b.data(), n * sizeof(cs_agent_view)) == 0);
@@ -108,14 +109,14 @@ int main() {
     CHECK(cs_synchronize(one) == 0 && cs_mesh_synchronize(mesh) == 0);
     if (report) CHECK(r1.n_agents == rm.n_agents && r1.n_spawned == rm.n_spawned && r1.n_destroyed == rm.n_destroyed);
   }
-  const size_t n = same();
+  const size_t n = same("after 150 steps");
   CHECK(n > 9025);  // the lane has spawned
 
   // re-cut (the state must not change), then merged queries against the single engine's
   uint64_t counts[4];
   CHECK(cs_mesh_recut(mesh) == 0 && cs_mesh_tile_counts(mesh, counts) == 0);
   CHECK(counts[0] + counts[1] + counts[2] + counts[3] == n);
-  same();
+  same("after the re-cut");
   const double q[4] = {60.0, 60.0, 45.0, 75.5}, rad[2] = {3.0, 1.5};
   uint64_t ids_a[2 * 256], ids_b[2 * 256], cnt_a[2], cnt_b[2];
   CHECK(cs_query_radius_batch(one, 2, q, rad, 256, ids_a, cnt_a, nullptr, nullptr) == 0);
@@ -131,7 +132,7 @@ int main() {
   CHECK(cs_remove_agent(one, 17) == 0 && cs_mesh_remove_agent(mesh, 17) == 0);
   CHECK(cs_mesh_remove_agent(mesh, 17) == 2);
   for (int k = 0; k < 60; ++k) CHECK(cs_step(one, 0.05, nullptr) == 0 && cs_mesh_step(mesh, 0.05, nullptr) == 0);
-  same();
+  same("60 steps after the removal");
   cs_mesh_destroy(mesh);
   cs_destroy(one);
 

@@ -107,3 +107,52 @@ def test_kept_windows_on_the_tiles_of_a_mesh(monkeypatch):
     assert mesh.tile(0).kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS) >= steps // 2
     assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
     assert int(mesh.tile_counts().sum()) == n
+
+
+def test_queries_reads_and_removals_between_steps_leave_the_kept_windows_alone(monkeypatch):
+    """A radius query, a read-back or a removal between two steps sorts the agents outside any step: that sort's scan
+    used to clear the window count of the very list the next step was about to run on (nobody stepped: the crowd was
+    gone a step later), and on a tile it zeroed the owned count with no builder behind it to count again."""
+    pts, grid, extent, group = scenes.uniform_crowd(20000, seed=12, cell_size=2.0, room=4.0)
+
+    def build(flags):
+        sim = Simulation(LocationHash2D(**grid), flags=flags)
+        scenes.add_counterflow(sim, pts, group, scenes.CREEP_SPEED, LP, 2.0)
+        mid = (float(pts[:, 0].mean()), float(pts[:, 1].mean()))
+
+        def between(k):
+            if k % 7 == 3:
+                assert len(sim.get_neighbours_in_radius(3.0, mid)) > 5
+            if k % 7 == 5:
+                assert len(sim.read_agents()) == len(sim)
+            if k == 20:
+                sim.remove_agents(17)
+                sim.remove_agents(4242)
+        sim._between_steps = between
+        return sim
+    runs = _three_ways(monkeypatch, build, 45, report_every=15)
+    assert len(runs["kept"][0]) == len(pts) - 2
+
+
+def test_a_tile_nobody_stands_in_steps_on_fillers_alone(monkeypatch):
+    """The crowd stands in one tile of a 2 x 2 mesh; the slot count of the three empty tiles is a host-side upper bound
+    (what the halo buffers could deliver), large enough for the tiled kernel: their kept lists are fillers only, over
+    sorted arrays that hold no record.  (Those windows used to load 'slot 0' for their idle lanes and index the group
+    table with whatever lay there: a memory fault on an unlucky day.)"""
+    from rmf_crowdsim_amd.tiles import LocalTileMesh
+    n = 3200
+    pts = scenes.jittered_lattice(n, 0.75, (6.0, 96.0), 0.2, 5)
+    grid = dict(width=174.0, height=174.0, cell_size=3.0, offset=(0.0, 0.0))
+    monkeypatch.setenv("CS_CHECK_WINDOWS", "1")
+    single = Simulation(LocationHash2D(**grid))
+    mesh = LocalTileMesh(LocationHash2D(**grid), (2, 2), halo_cells=1, phases=1)
+    for t in (single, mesh):
+        t.add_agents(pts[: n // 2], StubHighLevelPlan((0.2, 0.3)), LP, 1.0)
+        t.add_agents(pts[n // 2:], StubHighLevelPlan((-0.3, 0.1)), LP, 0.8)
+    for _ in range(12):
+        single.step(0.05, report=False)
+        mesh.step(0.05, report=False)
+    counts = [len(e) for e in mesh.engines]
+    assert sorted(counts)[:3] == [0, 0, 0] and sum(counts) == n
+    assert sum(e.kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS) for e in mesh.engines) >= 20  # (the empty tiles too)
+    assert single.read_agents().tobytes() == mesh.read_agents().tobytes()

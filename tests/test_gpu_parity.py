@@ -674,7 +674,12 @@ def test_every_window_stays_on_the_lds_path(scene):
         sim.step(0.05, report=False)
     sim.synchronize()
     assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_OFF_LDS) == 0
-    assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_CHUNKED) == 0
+    # (a crowd of this size steps on the windows cut a step earlier, with 10 % room in them: a band the crowd's front has
+    # just entered fills faster than that for its first steps, and a window there owns more agents than the workgroup has
+    # threads: it walks them in two chunks, still in LDS.  Rare: under 0.1 % of the windows stepped.)
+    kept = sim.kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS)
+    assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_CHUNKED) <= (kept * len(pts) / 230) // 1000
+    assert (kept > 0) == (scene == "walking edge")
     assert len(sim) == len(pts)
 
 
