@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage (under gpurun): tools/keep_bench.sh [agents...] -- small crowds: the window builder in every step's own launch
-# (CS_WINDOWS_KEEP=0) against the builder on a second stream, one step ahead (the default), with 5 / 10 / 20 % of room
+# usage (under gpurun): tools/keep_bench.sh [agents...] -- small crowds: the window builder in every step's own scatter
+# launch (CS_WINDOWS_KEEP=0, "shadow 0") against stepping on the windows of the step before, cut by builder workgroups
+# inside the neighbour kernel's launch (the default, "shadow 1"), with 5 / 10 / 20 % of room in a window
 mkdir -p gpurun_out
 sizes=${@:-"125000"}
 for w in walk random creep; do
