@@ -94,7 +94,7 @@ void cs_destroy(cs_engine* e) {
   hipFree(e->route_desc_dev); hipFree(e->route_xy_dev); hipFree(e->route_book_dev); hipFree(e->hlp_scale_dev); hipFree(e->route_pending_dev);
   hipFree(e->groups_dev); hipFree(e->sinks_dev); hipFree(e->waypoints_dev);
   hipFree(e->src_cell_start); hipFree(e->src_sorted); hipFree(e->src_occupied);
-  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->blk_desc_back); hipFree(e->n_blocks_dev); hipFree(e->n_blocks_back); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev); hipFree(e->query_scratch);
+  hipFree(e->want_dev); hipFree(e->spawned_slots_dev); hipFree(e->spawn_scratch); hipHostFree(e->want_host); hipFree(e->blk_desc); hipFree(e->blk_desc_back); hipFree(e->n_blocks_dev); hipFree(e->n_blocks_back); hipFree(e->band_prefix); hipFree(e->tile_spill); hipFree(e->spawn_rec_dev); hipFree(e->find_dev); hipFree(e->step_flags_dev); hipFree(e->query_scratch); hipFree(e->scan_tile_sums);
   for (auto& t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -187,6 +187,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_WINDOWS_CAP")) e->tile_windows_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_CHECK_WINDOWS")) e->check_windows = atoi(v) != 0;
+  if (const char* v = getenv("CS_SCAN_ONEPASS")) e->scan_onepass = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_ROWS")) e->tile_rows = std::min<uint32_t>(TILE_MAX_OWN_ROWS, std::max(1, atoi(v)));
   if (const char* v = getenv("CS_TILE_TARGET")) e->tile_target = std::min<uint32_t>(4 * TILE_THREADS, std::max(32, atoi(v)));
   const bool is_tile = cfg && (cfg->tile_cx1 | cfg->tile_cy1);

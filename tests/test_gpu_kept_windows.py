@@ -156,3 +156,24 @@ def test_a_tile_nobody_stands_in_steps_on_fillers_alone(monkeypatch):
     assert sorted(counts)[:3] == [0, 0, 0] and sum(counts) == n
     assert sum(e.kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS) for e in mesh.engines) >= 20  # (the empty tiles too)
     assert single.read_agents().tobytes() == mesh.read_agents().tobytes()
+
+
+def test_one_pass_scan_and_two_launch_scan_sort_alike(monkeypatch):
+    """The cell scan is ONE launch (`k_scan_onepass`: a tile adds up the totals of the tiles before it as they are
+    published) for grids of up to 1,024 scan tiles and the two-launch form beyond; `CS_SCAN_ONEPASS=0` selects the
+    latter everywhere.  Same bytes either way, on a grid of 130 tiles with a walking crowd (cells change hands every
+    step) and source-sinks (slots beyond the live records)."""
+    pts, grid, extent, group = scenes.uniform_crowd(150000, seed=4, cell_size=1.0, room=6.0)
+    outs = []
+    for onepass in ("1", "0"):
+        monkeypatch.setenv("CS_SCAN_ONEPASS", onepass)
+        sim = Simulation(LocationHash2D(**grid))
+        scenes.add_walking_crowd(sim, pts, group, LP, 2.0)
+        x0, y0 = grid["offset"][0] + 3.0, grid["offset"][1] + 3.0
+        for k in range(4):
+            sim.add_source_sink(SourceSink((x0, y0 + 2.0 * k), 0.5, MonotonicCrowd(1000.0), StubHighLevelPlan((0.0, 1.0)), LP,
+                                           [(x0, y0 + 2.0 * k + 4.0)], False, 2.0))
+        for k in range(40):
+            sim.step(0.05, report=(k % 13 == 12))
+        outs.append(sim.read_agents())
+    assert len(outs[0]) > 150000 and outs[0].tobytes() == outs[1].tobytes()
