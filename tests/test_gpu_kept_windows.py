@@ -161,7 +161,7 @@ def test_a_tile_nobody_stands_in_steps_on_fillers_alone(monkeypatch):
 def test_one_pass_scan_and_two_launch_scan_sort_alike(monkeypatch):
     """The cell scan is ONE launch (`k_scan_onepass`: a tile adds up the totals of the tiles before it as they are
     published) for grids of up to 1,024 scan tiles and the two-launch form beyond; `CS_SCAN_ONEPASS=0` selects the
-    latter everywhere.  Same bytes either way, on a grid of 130 tiles with a walking crowd (cells change hands every
+    latter everywhere.  Same bytes either way, on a grid of some sixty scan tiles with a walking crowd (cells change hands every
     step) and source-sinks (slots beyond the live records)."""
     pts, grid, extent, group = scenes.uniform_crowd(150000, seed=4, cell_size=1.0, room=6.0)
     outs = []
