@@ -679,7 +679,7 @@ def test_every_window_stays_on_the_lds_path(scene):
     # threads: it walks them in two chunks, still in LDS.  Rare: under 0.1 % of the windows stepped.)
     kept = sim.kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS)
     assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_CHUNKED) <= (kept * len(pts) / 230) // 1000
-    assert (kept > 0) == (scene == "walking edge")
+    assert kept > 0   # (crowds of up to 300,000 slots step on kept windows)
     assert len(sim) == len(pts)
 
 
