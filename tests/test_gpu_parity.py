@@ -7,6 +7,7 @@ Tolerances (fp32 device state vs the f64 oracle), stated once:
 Integer results (ids, counts, event order, neighbour sets) are exact.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -635,6 +636,7 @@ def test_windows_beyond_the_launch_fail_the_step_loudly(report, monkeypatch):
     scene needs: the builder and the kernel count the windows they could not list / run, and the engine
     refuses to go on (their agents were not stepped) instead of returning a crowd that silently lost them."""
     monkeypatch.setenv("CS_TILE_WINDOWS_CAP", "40")
+    monkeypatch.delenv("CS_CHECK_WINDOWS", raising=False)  # (the debugging check would refuse the list before the launch)
     s, _ = _crowd(Simulation, 30000, 2.0, 2.0, scenes.CREEP_SPEED, flags=2)
     with pytest.raises(RuntimeError, match="more band windows than the step kernel's launch"):
         s.step(0.05, report=report)
@@ -679,7 +681,7 @@ def test_every_window_stays_on_the_lds_path(scene):
     # threads: it walks them in two chunks, still in LDS.  Rare: under 0.1 % of the windows stepped.)
     kept = sim.kernel_stat(_abi.CS_STAT_STEPS_ON_KEPT_WINDOWS)
     assert sim.kernel_stat(_abi.CS_STAT_WINDOWS_CHUNKED) <= (kept * len(pts) / 230) // 1000
-    assert kept > 0   # (crowds of up to 300,000 slots step on kept windows)
+    assert kept > 0 or os.environ.get("CS_WINDOWS_KEEP") == "0"   # (crowds of up to 300,000 slots step on kept windows)
     assert len(sim) == len(pts)
 
 
