@@ -316,11 +316,20 @@ struct Zanlungo : LocalPlanner {
   Real agent_scale, obstacle_scale, reaction_time, force_distance, agent_mass, agent_radius;
   std::unordered_map<uint64_t, Real> agent_priorities;  // :17,46 — created empty, no setter
 
+  // Conditioning probe, NOT the reference (off by default; only oracle_fast_steps_guarded sets it): a pair that is not
+  // inside the collision distance and whose |rel_vel|^2 is below 1e-30 counts as "never collides".  The reference
+  // computes a collision 1e13 s or more ahead for such a pair (whose force term is exp(-huge) = 0) unless a and b^2
+  // underflow, and then reads it as "colliding now" (spurious_collision below): in f64 that strikes once per 1e6
+  // agent-steps, in a plain f32 transcription within tens of steps of any scene with real forces, so an f32 leg of a
+  // long three-way comparison exists only with this guard (the engine has the same one: DESIGN.md section 2).
+  bool guard_underflow = false;
+
   // :49-74
   Real time_to_collision(V2 rel_vel, V2 rel_pos) const {
     Real a = norm2(rel_vel);
     Real b = Real(2) * dot(rel_vel, rel_pos);
     Real c = norm2(rel_pos) - agent_radius * agent_radius;
+    if (guard_underflow && c > Real(0) && a < Real(1e-30)) return kInf;
     Real disc = b * b - Real(4) * a * c;
     if (disc < Real(0)) return kInf;
     Real root = std::sqrt(disc);
@@ -1310,13 +1319,24 @@ uint64_t oracle_shell_crossings(cs_engine* e) { return e->last_shell_crossings; 
 // preferred velocities (the bench scene), no source-sinks.  Positions are updated in place;
 // returns the seconds spent in the step loop, or a negative value if an agent left the grid.
 // ---------------------------------------------------------------------------
-double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
-                         double force_distance, double agent_mass, double agent_radius, double eyesight,
-                         double width, double height, double cell_size, double off_x, double off_y,
-                         double dt_seconds, uint32_t steps, int threads, uint8_t* spurious_out) {
+}  // extern "C"
+// flags of oracle_fast_steps_ex (test infrastructure; 0 = the reference's arithmetic as restated above)
+//   1  Zanlungo::guard_underflow
+//   2  "cell-relative": positions are KEPT in f64 whatever Real is, and every agent's update is computed in Real on
+//      positions taken relative to the origin of the agent's own cell (rounded to Real once).  The model only ever uses
+//      differences of positions, so in exact arithmetic nothing changes; in an f32 build the rounding of a coordinate is
+//      then that of a number below a few cells (1e-7 m) instead of that of a global coordinate (3e-5 m at 500 m).  This
+//      is the precision class of the HIP engine's layout in an independent implementation: the
+//      f32 leg of the long three-way comparisons.
+static double fast_steps_impl(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
+                              double force_distance, double agent_mass, double agent_radius, double eyesight,
+                              double width, double height, double cell_size, double off_x, double off_y,
+                              double dt_seconds, uint32_t steps, int threads, uint8_t* spurious_out, int flags) {
   // spurious_out (may be null): set to 1 for every agent whose t_i came out 0 through an underflowed pair in some
   // step (Zanlungo::spurious_collision)
+  const bool relative = (flags & 2) != 0;
   Zanlungo lp;
+  lp.guard_underflow = (flags & 1) != 0;
   lp.agent_scale = (Real)agent_scale;
   lp.obstacle_scale = Real(1);
   lp.reaction_time = Real(0);
@@ -1326,6 +1346,7 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
   const uint64_t nx = (uint64_t)(width / cell_size), n_rows = (uint64_t)(height / cell_size);
   const uint64_t ncells = nx * n_rows;
   std::vector<Agent> cur(n), nxt(n);
+  std::vector<double> pos(relative ? 2 * n : 0), pos_nxt(relative ? 2 * n : 0);  // (flag 2: the positions proper)
   for (uint64_t i = 0; i < n; ++i) {
     Agent& a = cur[i];
     a = Agent{};
@@ -1333,7 +1354,10 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
     a.position = {(Real)xy[2 * i], (Real)xy[2 * i + 1]};
     a.velocity = {(Real)vel_xy[2 * i], (Real)vel_xy[2 * i + 1]};
     a.eyesight_range = (Real)eyesight;
+    if (relative) pos[2 * i] = xy[2 * i], pos[2 * i + 1] = xy[2 * i + 1];
   }
+  auto px = [&](uint64_t i) { return relative ? pos[2 * i] : (double)cur[i].position.x; };
+  auto py = [&](uint64_t i) { return relative ? pos[2 * i + 1] : (double)cur[i].position.y; };
   std::vector<uint32_t> cell_of(n), start(ncells + 1), order(n);
   bool failed = false;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1344,7 +1368,7 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
     // cells in the reference's layout (x_idx * nx + y_idx); members in ascending id
     std::fill(start.begin(), start.end(), 0u);
     for (uint64_t i = 0; i < n; ++i) {
-      const double fx = ((double)cur[i].position.x - off_x) / cell_size, fy = ((double)cur[i].position.y - off_y) / cell_size;
+      const double fx = (px(i) - off_x) / cell_size, fy = (py(i) - off_y) / cell_size;
       const uint64_t cx = fx > 0 ? (uint64_t)fx : 0, cy = fy > 0 ? (uint64_t)fy : 0;
       const uint64_t flat = cx * nx + cy;
       if (flat >= ncells) {
@@ -1364,28 +1388,44 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
 #pragma omp parallel
     {
       std::vector<const Agent*> nearby;
+      std::vector<Agent> local;  // (flag 2: the neighbours' records with positions relative to this agent's cell)
 #pragma omp for schedule(dynamic, 256)
       for (long long k = 0; k < (long long)n; ++k) {
         const uint32_t i = order[k];  // walk the agents cell by cell: neighbours stay in cache
         Agent me = cur[i];
         me.preferred_vel = {(Real)pref_xy[2 * i], (Real)pref_xy[2 * i + 1]};
         const Real r = me.eyesight_range;
-        const long long lx = (long long)std::floor(((double)me.position.x - (double)r - off_x) / cell_size);
-        const long long hx = (long long)std::floor(((double)me.position.x + (double)r - off_x) / cell_size);
-        const long long ly = (long long)std::floor(((double)me.position.y - (double)r - off_y) / cell_size);
-        const long long hy = (long long)std::floor(((double)me.position.y + (double)r - off_y) / cell_size);
+        const double mx = px(i), my = py(i);
+        // the origin everything is measured from under flag 2: this agent's cell
+        const double ox = relative ? off_x + std::floor((mx - off_x) / cell_size) * cell_size : 0.0;
+        const double oy = relative ? off_y + std::floor((my - off_y) / cell_size) * cell_size : 0.0;
+        if (relative) me.position = {(Real)(mx - ox), (Real)(my - oy)};
+        const long long lx = (long long)std::floor((mx - (double)r - off_x) / cell_size);
+        const long long hx = (long long)std::floor((mx + (double)r - off_x) / cell_size);
+        const long long ly = (long long)std::floor((my - (double)r - off_y) / cell_size);
+        const long long hy = (long long)std::floor((my + (double)r - off_y) / cell_size);
         nearby.clear();
+        local.clear();
         for (long long x = lx; x <= hx; ++x)
           for (long long y = ly; y <= hy; ++y) {
             if (x < 0 || y < 0) continue;
             const unsigned long long flat = (unsigned long long)x * nx + (unsigned long long)y;
             if (flat >= ncells) continue;
             for (uint32_t q = start[flat]; q < start[flat + 1]; ++q) {
-              const Agent& o = cur[order[q]];
+              const uint32_t j = order[q];
+              const Agent& o = cur[j];
               if (o.agent_id == me.agent_id) continue;
-              if (norm(o.position - me.position) < r) nearby.push_back(&o);
+              if (!relative) {
+                if (norm(o.position - me.position) < r) nearby.push_back(&o);
+              } else {
+                Agent rel = o;
+                rel.position = {(Real)(pos[2 * j] - ox), (Real)(pos[2 * j + 1] - oy)};
+                if (norm(rel.position - me.position) < r) local.push_back(rel);
+              }
             }
           }
+        if (relative)
+          for (const Agent& o : local) nearby.push_back(&o);
         Real t_i = kInf;
         for (const Agent* o : nearby) {
           const Real t = lp.time_to_collision(o->velocity - me.velocity, o->position - me.position);
@@ -1398,21 +1438,45 @@ double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* p
           for (const Agent* o : nearby) force = force + lp.compute_agent_force(me, *o, t_i);
         const V2 vel = me.preferred_vel + force * (Real(1) / lp.agent_mass);
         Agent out = cur[i];
-        out.position = me.position + vel * dt;
         out.velocity = vel;
+        if (!relative) {
+          out.position = me.position + vel * dt;
+        } else {
+          // the step itself in Real relative to the cell (as the engine's layout does), kept in f64
+          const V2 moved = me.position + vel * dt;
+          pos_nxt[2 * i] = ox + (double)moved.x;
+          pos_nxt[2 * i + 1] = oy + (double)moved.y;
+          out.position = {(Real)pos_nxt[2 * i], (Real)pos_nxt[2 * i + 1]};
+        }
         nxt[i] = out;
       }
     }
     cur.swap(nxt);
+    if (relative) pos.swap(pos_nxt);
   }
   const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (uint64_t i = 0; i < n; ++i) {
-    xy[2 * i] = (double)cur[i].position.x;
-    xy[2 * i + 1] = (double)cur[i].position.y;
+    xy[2 * i] = px(i);
+    xy[2 * i + 1] = py(i);
     vel_xy[2 * i] = (double)cur[i].velocity.x;
     vel_xy[2 * i + 1] = (double)cur[i].velocity.y;
   }
   return failed ? -1.0 : el;
 }
-
+extern "C" {
+double oracle_fast_steps(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
+                         double force_distance, double agent_mass, double agent_radius, double eyesight,
+                         double width, double height, double cell_size, double off_x, double off_y,
+                         double dt_seconds, uint32_t steps, int threads, uint8_t* spurious_out) {
+  return fast_steps_impl(n, xy, vel_xy, pref_xy, agent_scale, force_distance, agent_mass, agent_radius, eyesight, width,
+                         height, cell_size, off_x, off_y, dt_seconds, steps, threads, spurious_out, 0);
+}
+// The same with the flags above (the f32 build's leg of the long three-way comparisons: flags = 3).
+double oracle_fast_steps_ex(uint64_t n, double* xy, double* vel_xy, const double* pref_xy, double agent_scale,
+                            double force_distance, double agent_mass, double agent_radius, double eyesight,
+                            double width, double height, double cell_size, double off_x, double off_y,
+                            double dt_seconds, uint32_t steps, int threads, uint8_t* spurious_out, int flags) {
+  return fast_steps_impl(n, xy, vel_xy, pref_xy, agent_scale, force_distance, agent_mass, agent_radius, eyesight, width,
+                         height, cell_size, off_x, off_y, dt_seconds, steps, threads, spurious_out, flags);
+}
 }  // extern "C"

@@ -36,10 +36,10 @@ def load_oracle(kind="f64"):
     lib.oracle_count_shell_crossings.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.oracle_shell_crossings.restype = ctypes.c_uint64
     lib.oracle_shell_crossings.argtypes = [ctypes.c_void_p]
-    lib.oracle_fast_steps.restype = ctypes.c_double
-    lib.oracle_fast_steps.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
-                                      [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int,
-                                                                 ctypes.POINTER(ctypes.c_uint8)])
+    lib.oracle_fast_steps_ex.restype = ctypes.c_double
+    lib.oracle_fast_steps_ex.argtypes = ([ctypes.c_uint64] + [ctypes.POINTER(ctypes.c_double)] * 3 +
+                                         [ctypes.c_double] * 11 + [ctypes.c_uint32, ctypes.c_int,
+                                                                    ctypes.POINTER(ctypes.c_uint8), ctypes.c_int])
     lib.oracle_degenerate_flips.restype = ctypes.c_uint64
     lib.oracle_degenerate_flips.argtypes = [ctypes.c_void_p]
     lib.oracle_spurious_victims.restype = ctypes.c_size_t
@@ -90,19 +90,26 @@ class OracleSimulationF32(OracleSimulation):
     _kind = "f32"
 
 
-def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=None, spurious=None):
+def fast_steps(pts, pref, zanlungo, eyesight, grid, dt, steps, threads=0, vel=None, spurious=None, kind="f64",
+               guarded=False, cell_relative=False):
     """The OpenMP / cell-sorted CPU baseline (oracle_fast_steps): same arithmetic as the oracle,
-    not the reference's data structures.  Returns (positions, velocities, seconds).  `spurious`: a uint8 array
-    of len(pts) that gets a 1 for every agent whose t_i came out 0 through an underflowed pair in some step."""
+    not the reference's data structures.  Returns (positions, velocities, seconds; negative = an agent left the grid).
+    `spurious`: a uint8 array of len(pts) that gets a 1 for every agent whose t_i came out 0 through an underflowed pair
+    in some step.  kind = "f32": the f32 build of the same code (state and arithmetic in f32, global coordinates).
+    guarded: with Zanlungo::guard_underflow (a pair outside the collision distance with |rel_vel|^2 < 1e-30 never
+    collides): the only way a plain f32 reading of the reference survives a long scene with real forces.
+    cell_relative: positions kept in f64, every agent's update computed in `kind`'s type on positions relative to its own
+    cell (the precision class of the HIP engine's layout, implemented independently: oracle_fast_steps_ex, flag 2)."""
     import numpy as np
-    lib = load_oracle("f64")
+    lib = load_oracle(kind)
     xy = np.ascontiguousarray(pts, dtype=np.float64).copy()
     v = np.zeros_like(xy) if vel is None else np.ascontiguousarray(vel, dtype=np.float64).copy()
     pv = np.ascontiguousarray(pref, dtype=np.float64)
     dp = ctypes.POINTER(ctypes.c_double)
     A, _, _, D, m, R = zanlungo
-    sec = lib.oracle_fast_steps(len(xy), xy.ctypes.data_as(dp), v.ctypes.data_as(dp), pv.ctypes.data_as(dp),
-                                A, D, m, R, eyesight, grid["width"], grid["height"], grid["cell_size"],
-                                grid["offset"][0], grid["offset"][1], dt, steps, threads,
-                                None if spurious is None else spurious.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    sec = lib.oracle_fast_steps_ex(len(xy), xy.ctypes.data_as(dp), v.ctypes.data_as(dp), pv.ctypes.data_as(dp),
+                                   A, D, m, R, eyesight, grid["width"], grid["height"], grid["cell_size"],
+                                   grid["offset"][0], grid["offset"][1], dt, steps, threads,
+                                   None if spurious is None else spurious.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                   (1 if guarded else 0) | (2 if cell_relative else 0))
     return xy, v, sec
