@@ -6,7 +6,7 @@
 //   HighLevelPlanner      highlevel_planners/highlevel_planners.rs:8-16
 //   LocalPlanner / Zanlungo / NoLocalPlan   local_planners/{local_planner,zanlungo,no_local_plan}.rs
 //   LocationHash2D        spatial_index/location_hash_2d.rs:33-51
-//   SourceSink / CrowdGenerator / MonotonicCrowd      source_sink/source_sink.rs:30-101
+//   SourceSink / CrowdGenerator / MonotonicCrowd / PoissonCrowd   source_sink/source_sink.rs:30-101
 // Header-only; link against libcrowdstep_hip.so (the HIP engine).  There is no CPU path.
 #ifndef CROWDSIM_HPP
 #define CROWDSIM_HPP
@@ -14,6 +14,7 @@
 #include <chrono>
 #include <map>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -217,6 +218,18 @@ struct MonotonicCrowd : CrowdGenerator {  // source_sink.rs:85-101
   void fill(cs_source_sink_desc* d) const override {
     d->generator_kind = CS_GEN_MONOTONIC;
     d->rate = rate;
+  }
+};
+
+struct PoissonCrowd : CrowdGenerator {  // source_sink.rs:63-82: unseeded like the reference's thread_rng; host callback
+  double rate;
+  explicit PoissonCrowd(double r) : rate(r) {}
+  std::size_t get_number_to_spawn(std::chrono::duration<double> t) const override {
+    const double rt = t.count() * rate;
+    if (!(rt > 0.0)) return 0;  // (the reference panics here: Poisson::new(rt).unwrap(), source_sink.rs:79; no exception may
+                                //  cross the C ABI this is called through)
+    thread_local std::mt19937_64 rng{std::random_device{}()};
+    return (std::size_t)std::poisson_distribution<unsigned long long>(rt)(rng);
   }
 };
 

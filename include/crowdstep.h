@@ -350,8 +350,10 @@ uint64_t cs_device_bytes(cs_engine*);
  * by a change of the agents in between) */
 #define CS_STAT_EXCHANGES_AHEAD 2u
 #define CS_STAT_EXCHANGES_AHEAD_USED 3u
-/* steps of a small crowd that ran on the band windows of an earlier step (the window builder runs every 4th step there:
- * windows built to tile their band completely, with room to spare, stay correct while the agents move) */
+/* steps of a small crowd (at most 300,000 slots) that ran on the band windows cut ONE STEP EARLIER: the builder runs in
+ * every step, as workgroups leading the neighbour kernel's own launch, and cuts the windows the NEXT step runs on (cut to
+ * tile their band completely, with room to spare, so they stay correct while the agents move one step).  The environment
+ * variable CS_WINDOWS_KEEP is a switch, not a period: 0 = cut every step's windows in its own scatter launch */
 #define CS_STAT_STEPS_ON_KEPT_WINDOWS 4u
 uint64_t cs_kernel_stat(cs_engine*, uint32_t which);
 

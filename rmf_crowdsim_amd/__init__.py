@@ -6,14 +6,14 @@ Host-side mirror of the reference trait surface over the C ABI of the HIP engine
 from ._abi import (CS_CFG_DEFAULT, CS_CFG_DENSE, CS_CFG_FORCE_GATHER, CS_CFG_FORCE_TILED)
 from .simulation import (Agent, CrowdGenerator, CrowdSimError, EventListener, HighLevelPlanner,
                          IdParityHighLevelPlan, LocalPlanner, LocationHash2D, MonotonicCrowd,
-                         NoHighLevelPlan, NoLocalPlan, RouteFollower, SeededPoissonCrowd, Simulation,
+                         NoHighLevelPlan, NoLocalPlan, PoissonCrowd, RouteFollower, SeededPoissonCrowd, Simulation,
                          SourceSink, SpatialIndex,
                          StubHighLevelPlan, Zanlungo)
 
 __all__ = [
     "Agent", "CrowdGenerator", "CrowdSimError", "EventListener", "HighLevelPlanner",
     "IdParityHighLevelPlan", "LocalPlanner", "LocationHash2D", "MonotonicCrowd",
-    "NoHighLevelPlan", "NoLocalPlan", "RouteFollower", "SeededPoissonCrowd", "Simulation",
+    "NoHighLevelPlan", "NoLocalPlan", "PoissonCrowd", "RouteFollower", "SeededPoissonCrowd", "Simulation",
     "SourceSink", "SpatialIndex",
     "StubHighLevelPlan", "Zanlungo", "CS_CFG_DEFAULT", "CS_CFG_DENSE", "CS_CFG_FORCE_GATHER",
     "CS_CFG_FORCE_TILED",

@@ -276,6 +276,20 @@ int cs_add_agents(cs_engine* e, const double* xy, size_t n, uint32_t hlp, uint32
 int cs_remove_agent(cs_engine* e, uint64_t id) {
   hipSetDevice(e->device);
   e->halo_invalidate();  // also where the agent is not found: every tile is asked, all must agree on what follows
+  for (size_t k = 0; k < e->limbo.size(); ++k)
+    if (e->limbo[k].id == id) {  // an agent the index never took (lib.rs:133-149) is removed like any other (:176-192)
+      const HostGroup& g = e->groups[e->limbo[k].group];
+      const cs_hlp_desc& p = e->hlps[g.hlp];
+      if (p.kind == CS_HLP_CALLBACK && p.remove_agent) p.remove_agent(p.user, id);
+      e->limbo.erase(e->limbo.begin() + (long)k);
+      cs_event ev;
+      ev.kind = CS_EVENT_DESTROYED;
+      ev.source_sink = UINT32_MAX;
+      ev.id = id;
+      ev.x = ev.y = 0;
+      if (e->record_events) e->events.push_back(ev);
+      return 0;
+    }
   if (int rc = e->refresh_counts()) return rc;
   uint32_t found[2] = {0xFFFFFFFFu, 0u};
   if (id < 0xFFFFFFFFull && e->n_slots) {
@@ -410,7 +424,7 @@ int cs_synchronize(cs_engine* e) {
 size_t cs_agent_count(cs_engine* e) {
   hipSetDevice(e->device);
   e->refresh_counts();
-  return (size_t)e->n_alive_host;
+  return (size_t)e->n_alive_host + e->limbo.size();
 }
 
 size_t cs_read_agents(cs_engine* e, cs_agent_view* out, size_t cap) {
@@ -431,6 +445,19 @@ size_t cs_read_agents(cs_engine* e, cs_agent_view* out, size_t cap) {
     out[k].vy = h.vel[i].y;
     out[k].next_waypoint = meta_waypoint(e->gdev, h.meta[i]);
     out[k].eyesight_range = e->groups[meta_group(e->gdev, h.meta[i])].eyesight;
+  }
+  if (!e->limbo.empty()) {  // the agents the index never took: as created (lib.rs:133-144), in id order with the rest
+    for (const cs_engine::LimboAgent& l : e->limbo) {
+      if (n >= cap) break;
+      cs_agent_view v;
+      std::memset(&v, 0, sizeof v);
+      v.id = l.id;
+      v.x = l.x;
+      v.y = l.y;
+      v.eyesight_range = e->groups[l.group].eyesight;
+      out[n++] = v;
+    }
+    std::sort(out, out + n, [](const cs_agent_view& a, const cs_agent_view& b) { return a.id < b.id; });
   }
   return n;
 }
@@ -1136,7 +1163,7 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
   }
   // CS_CFG_TILE_OVERLAP: the step puts the border windows' launch on the second stream; the next
   // step's exchange follows them there while the interior windows still run on the engine's stream
-  e->overlap_ready = e->split_margin() != 0u && e->rccl_comm != nullptr;
+  e->overlap_ready = e->split_margin() != 0u && e->rccl_comm != nullptr && !e->no_exchange_ahead;
   const int rc = e->step(dt_seconds, report);
   e->overlap_ready = false;
   if (rc == 0) e->steps_done += 1;

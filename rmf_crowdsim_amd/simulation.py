@@ -315,6 +315,23 @@ class MonotonicCrowd(CrowdGenerator):
         return []
 
 
+class PoissonCrowd(CrowdGenerator):
+    """PoissonCrowd::new(rate), source_sink.rs:63-82: Poisson(dt * rate) drawn from an UNSEEDED generator on every
+    call (the reference's `thread_rng`), so two runs differ, as they do in the reference; asked on the host through the
+    CrowdGenerator callback (a tile mesh refuses it: its tiles must draw alike).  SeededPoissonCrowd is the
+    reproducible form."""
+
+    def __init__(self, rate):
+        self.rate = float(rate)
+        self._rng = np.random.default_rng()  # OS entropy: unseeded like thread_rng
+
+    def get_number_to_spawn(self, time_elapsed):
+        rt = time_elapsed.total_seconds() * self.rate
+        if not rt > 0.0:  # statrs' Poisson::new(lambda <= 0 or NaN) is an Err that the reference unwraps: a panic
+            raise ValueError("PoissonCrowd: dt * rate must be positive (Poisson::new(rt).unwrap(), source_sink.rs:79)")
+        return int(self._rng.poisson(rt))
+
+
 class SeededPoissonCrowd(CrowdGenerator):
     """Seeded replacement for PoissonCrowd (source_sink.rs:63-82, whose
     thread_rng cannot be seeded): Poisson(dt * rate) from a counter-based

@@ -149,15 +149,23 @@ pub(crate) unsafe extern "C" fn lp_batch_trampoline(user: *mut c_void, n_agents:
         next_waypoint: r.next_waypoint as usize,
         eyesight_range: r.eyesight_range,
     };
-    for k in 0..n_agents {
-        let (b, e) = (*nb_begin.add(k) as usize, *nb_begin.add(k + 1) as usize);
-        let nearby: Vec<Agent> = (b..e).map(|q| view(&*neighbours.add(q))).collect();
-        let recommended = Vector2::new(*recommended_xy.add(2 * k), *recommended_xy.add(2 * k + 1));
-        let v = p.get_desired_velocity(&view(&*agents.add(k)), &nearby, recommended);
-        *out_velocity_xy.add(2 * k) = v.x;
-        *out_velocity_xy.add(2 * k + 1) = v.y;
+    // A panic inside the user's planner must not unwind across `extern "C"` either (an abort on current toolchains,
+    // undefined behaviour on older ones): it is caught here and fails the step ("a host LocalPlanner failed"), as the
+    // C++ (catch ...) and Python (try / except) thunks do.
+    let outcome = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+        for k in 0..n_agents {
+            let (b, e) = (*nb_begin.add(k) as usize, *nb_begin.add(k + 1) as usize);
+            let nearby: Vec<Agent> = (b..e).map(|q| view(&*neighbours.add(q))).collect();
+            let recommended = Vector2::new(*recommended_xy.add(2 * k), *recommended_xy.add(2 * k + 1));
+            let v = p.get_desired_velocity(&view(&*agents.add(k)), &nearby, recommended);
+            *out_velocity_xy.add(2 * k) = v.x;
+            *out_velocity_xy.add(2 * k + 1) = v.y;
+        }
+    }));
+    match outcome {
+        Ok(()) => 0,
+        Err(_) => 1,
     }
-    0
 }
 
 unsafe extern "C" fn hlp_set_target_trampoline(user: *mut c_void, id: u64, pos_x: f64, pos_y: f64, point_x: f64,

@@ -160,7 +160,32 @@ static void test_event_listener_source_sink_api_on_a_mesh() {
   }
 }
 
+// PoissonCrowd (source_sink.rs:63-82): unseeded, so only its statistics can be checked.  dt * rate = 0.5: a sink whose
+// source is always free (the walker leaves 1 m per step) spawns in a step with probability 1 - e^-0.5 = 0.393, one agent
+// at most (lib.rs:207-219).
+static void test_poisson_crowd() {
+  Simulation sim(LocationHash2D(1000.0, 1000.0, 20.0, Point{-500.0, -500.0}));
+  auto ss = std::make_shared<SourceSink>();
+  ss->source = Vec2f{0.0, 0.0};
+  ss->waypoints = {Vec2f{400.0, 0.0}};
+  ss->radius_sink = 1.0;
+  ss->crowd_generator = std::make_shared<PoissonCrowd>(0.5);
+  ss->high_level_planner = std::make_shared<StubHighLevelPlan>(Vec2f{1.0, 0.0});
+  ss->local_planner = std::make_shared<NoLocalPlan>();
+  ss->agent_eyesight_range = 5.0;
+  ss->loop_forever = false;
+  sim.add_source_sink(ss);
+  for (int k = 0; k < 300; ++k) sim.step(std::chrono::duration<double>(1.0));
+  const double spawned = (double)sim.agents.size();  // nobody reaches the sink within 300 m
+  CHECK(spawned > 300 * 0.393 - 5 * 8.5 && spawned < 300 * 0.393 + 5 * 8.5);  // +- 5 sigma
+  PoissonCrowd g(40.0);
+  double sum = 0;
+  for (int k = 0; k < 4000; ++k) sum += (double)g.get_number_to_spawn(std::chrono::duration<double>(0.05));
+  CHECK(std::fabs(sum / 4000 - 2.0) < 0.15);
+}
+
 int main() {
+  test_poisson_crowd();
   test_event_listener_source_sink_api_on_a_mesh();
   test_user_local_planner();
   test_snapshots();
@@ -168,6 +193,6 @@ int main() {
   test_event_listener_source_sink_api();
   test_index_out_of_bounds_is_an_error();
   test_viz_scene();
-  std::printf("7 passed\n");
+  std::printf("8 passed\n");
   return 0;
 }

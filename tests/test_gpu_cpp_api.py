@@ -41,4 +41,4 @@ def test_reference_step_tests_in_cpp():
     exe = build_cpp_test()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
-    assert out.returncode == 0 and "7 passed" in out.stdout
+    assert out.returncode == 0 and "8 passed" in out.stdout

@@ -18,7 +18,7 @@ LP = Zanlungo(*scenes.METRIC_ZANLUNGO)
 
 def _three_ways(monkeypatch, build, steps, report_every=25):
     runs = {}
-    for name, keep, flags in (("kept", "4", 2), ("every", "0", 2), ("gather", "0", 1)):
+    for name, keep, flags in (("kept", "1", 2), ("every", "0", 2), ("gather", "0", 1)):
         monkeypatch.setenv("CS_WINDOWS_KEEP", keep)
         sim = build(flags)
         for k in range(steps):
@@ -94,7 +94,7 @@ def test_kept_windows_on_the_tiles_of_a_mesh(monkeypatch):
     pts, grid, extent, group = scenes.uniform_crowd(n, seed=9, cell_size=2.0, room=scenes.WALK_SPEED * 0.05 * (steps + 8) + 4.0)
     monkeypatch.setenv("CS_WINDOWS_KEEP", "0")
     single = Simulation(LocationHash2D(**grid), flags=1)
-    monkeypatch.setenv("CS_WINDOWS_KEEP", "4")
+    monkeypatch.setenv("CS_WINDOWS_KEEP", "1")
     mesh = NativeTileMesh(LocationHash2D(**grid), (2, 2), 1, density_per_cell=15.0, weights=pts)
     for t in (single, mesh):
         scenes.add_walking_crowd(t, pts, group, LP, 2.0)

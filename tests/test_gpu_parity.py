@@ -15,7 +15,7 @@ import pytest
 from oracle_sim import OracleSimulation
 from rmf_crowdsim_amd import (CrowdSimError, IdParityHighLevelPlan, LocationHash2D, MonotonicCrowd,
                               NoLocalPlan, SeededPoissonCrowd, Simulation, SourceSink,
-                              StubHighLevelPlan, Zanlungo, HighLevelPlanner, RouteFollower)
+                              StubHighLevelPlan, Zanlungo, HighLevelPlanner, RouteFollower, EventListener)
 from rmf_crowdsim_amd import scenes
 from test_oracle_reference_kats import MockEventListener, run_event_listener_source_sink_api
 
@@ -79,6 +79,55 @@ def test_index_out_of_bounds_errors():
     with pytest.raises(CrowdSimError, match="Index out of bounds"):
         sim.step(1.0)
     assert tuple(sim.agents[0].position) == (3.5, 0.5)
+
+
+class _Ears(EventListener):
+    def __init__(self):
+        self.log = []
+
+    def agent_spawned(self, position, agent):
+        self.log.append(("spawned", int(agent)))
+
+    def agent_destroyed(self, agent):
+        self.log.append(("destroyed", int(agent)))
+
+
+def _refused_agent_story(sim):
+    """add_agents with a point beyond the grid (lib.rs:133-149), then steps, a further add, the removal."""
+    ears = _Ears()
+    sim.add_event_listener(ears)
+    out = []
+    with pytest.raises(CrowdSimError, match="Index out of bounds"):
+        sim.add_agents([(10.0, 10.0), (150.0, 10.0), (20.0, 20.0)], StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(), 2.0)
+    out.append(len(sim))
+    for _ in range(2):
+        with pytest.raises(CrowdSimError, match="Index out of bounds"):
+            sim.step(0.05)
+    a = sim.read_agents()
+    out.append((a["id"].tolist(), a["x"].tolist(), a["y"].tolist(), a["vx"].tolist(), a["eyesight_range"].tolist()))
+    out.append(list(sim.add_agents([(30.0, 30.0)], StubHighLevelPlan((1.0, 0.0)), NoLocalPlan(), 2.0)))
+    sim.remove_agents(1)
+    sim.step(0.05)
+    a = sim.read_agents()
+    out.append((a["id"].tolist(), np.round(a["x"], 6).tolist(), a["y"].tolist()))
+    with pytest.raises(CrowdSimError):
+        sim.remove_agents(1)
+    out.append(ears.log)
+    return out
+
+
+def test_an_agent_the_index_refused_exists_and_fails_every_step_until_it_is_removed():
+    """lib.rs:133-149: `add_agents` has put the agent into `agents` when `add_or_update` returns Err, so it exists (it
+    is counted, read back as created, removable, never announced to the listeners), the agents before it stay added, the
+    ones behind it never are, and every `step` fails on it with "Index out of bounds" (lib.rs:299-302) until it is
+    removed.  Round 4 dropped it; now the engine tells the oracle's story call for call."""
+    grid = dict(width=100.0, height=100.0, cell_size=2.0, offset=(0.0, 0.0))
+    sim, ora = both(grid)
+    got, want = _refused_agent_story(sim), _refused_agent_story(ora)
+    assert got == want
+    assert want[0] == 2 and want[1][0] == [0, 1] and want[1][1][1] == 150.0 and want[2] == [2]
+    assert want[3][0] == [0, 2] and want[3][1] == [10.05, 30.05]
+    assert want[4] == [("spawned", 0), ("spawned", 2), ("destroyed", 1)]
 
 
 def test_negative_side_is_clamped_not_an_error():
@@ -1602,7 +1651,8 @@ def test_random_api_sequences_give_the_oracle_s_results_and_errors(seed):
     la, lb = _api_sequence(Simulation, 12000 + seed), _api_sequence(OracleSimulation, 12000 + seed)
     for i, (x, y) in enumerate(zip(la, lb)):
         if x[0] == "add" and x[1] == "err":
-            break  # the reference keeps the agent it could not index (and fails every later step); the engine drops it
+            break  # both keep the agent the index refused and fail every later step on it (its own test above); the
+            #        oracle alone indexes it once its first step carries it inside the grid
         if x != y and x[0] == "final" and x[1] == y[1] == "ok" and x[2][0] == y[2][0]:
             assert np.allclose(x[2][1], y[2][1], atol=2e-3, equal_nan=True)
             assert np.allclose(x[2][2], y[2][2], atol=2e-3, equal_nan=True)

@@ -399,7 +399,7 @@ def test_a_failing_step_of_the_distributed_form_is_agreed_on(monkeypatch):
         mesh.step(0.05, report=True)
 
 
-def _rank_failing(rank, world, port, out_path):
+def _rank_failing(rank, world, port, out_path, layout=(2, 1)):
     import os
     import pickle
     import sys
@@ -411,9 +411,9 @@ def _rank_failing(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         grid = dict(width=40.0, height=40.0, cell_size=2.0, offset=(0.0, 0.0))
-        mesh = NativeTileMesh(LocationHash2D(**grid), (2, 1), 1, device=0, rank=rank, n_ranks=world,
+        mesh = NativeTileMesh(LocationHash2D(**grid), layout, 1, device=0, rank=rank, n_ranks=world,
                               host_transport=TorchHostTransport(dist))
-        _runaway_scene(mesh)   # the runaway lives on rank 1's tile (x >= 20)
+        _runaway_scene(mesh)   # the runaway lives on the last rank's tile (x >= 20, or >= 30)
         raised = None
         for k in range(60):
             try:
@@ -456,3 +456,69 @@ def test_two_ranks_agree_on_a_failure_and_nobody_hangs(tmp_path):
     assert r0 is not None and r1 is not None and r0[0] == r1[0] and 14 <= r0[0] <= 22
     assert "Index out of bounds" in r1[1] and "another rank" in r0[1]
     assert again0 == r0[1] and again1 == r1[1]
+
+
+def _failing_ranks(tmp_path, world, layout, port):
+    import pickle
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "failing")
+    procs = [ctx.Process(target=_rank_failing, args=(r, world, port, out, layout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung, "a rank was left waiting for a peer that had gone"
+    assert all(p.exitcode == 0 for p in procs)
+    return [pickle.load(open(f"{out}.{r}", "rb")) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,layout", [(2, (2, 1)), (4, (4, 1))])
+def test_ranks_agree_on_a_failure_through_the_halo_headers_alone(tmp_path, monkeypatch, world, layout):
+    """Review of round 4: without a report the ranks of a distributed mesh learnt of a failure at an all-reduce every 32
+    steps.  Now the failure word travels in the halo headers every neighbour receives every step anyway (no collective):
+    with the backstop all-reduce switched off (CS_MESH_CHECK_EVERY = 1,000,000) every rank leaves at the SAME call, within
+    tiles_x + tiles_y steps of the failing one (the single engine fails in step 14), the failing rank with the
+    reference's error, the others with "another rank", and nobody is left waiting.  4 x 1: the word crosses three tiles."""
+    monkeypatch.setenv("CS_MESH_CHECK_EVERY", "1000000")
+    got = _failing_ranks(tmp_path, world, layout, 29753 + world)
+    steps = [g[0][0] for g in got]
+    assert all(g[0] is not None for g in got) and len(set(steps)) == 1
+    assert 14 < steps[0] <= 14 + layout[0] + layout[1]
+    assert "Index out of bounds" in got[-1][0][1] and all("another rank" in g[0][1] for g in got[:-1])
+    assert all(g[1] == g[0][1] for g in got)
+
+
+@pytest.mark.gpu
+def test_the_backstop_alone_still_agrees(tmp_path, monkeypatch):
+    """CS_MESH_HEADER_AGREE=0: only the all-reduce every CS_MESH_CHECK_EVERY steps (round 4's agreement)."""
+    monkeypatch.setenv("CS_MESH_HEADER_AGREE", "0")
+    monkeypatch.setenv("CS_MESH_CHECK_EVERY", "8")
+    got = _failing_ranks(tmp_path, 2, (2, 1), 29759)
+    assert got[0][0][0] == got[1][0][0] and 14 <= got[0][0][0] <= 14 + 9
+    assert "Index out of bounds" in got[1][0][1] and "another rank" in got[0][0][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiling", [(2, 2), (3, 1)])
+def test_an_agent_the_index_refused_on_a_mesh(tiling):
+    """lib.rs:133-149 on a mesh: the agents before the refused one stay added ON EVERY TILE (the loop over the tiles used
+    to leave at the first tile that reported the failure: the tiles behind it missed them and their id counters fell
+    behind), the refused agent is counted, read and removable, every step fails until then without poisoning the mesh:
+    the single engine's story (== the oracle's, tests/test_gpu_parity.py) call for call."""
+    from test_gpu_parity import _refused_agent_story
+    grid = dict(width=100.0, height=100.0, cell_size=2.0, offset=(0.0, 0.0))
+    mesh = NativeTileMesh(LocationHash2D(**grid), tiling, 1)
+    single = Simulation(LocationHash2D(**grid))
+    got, want = _refused_agent_story(mesh), _refused_agent_story(single)
+    assert got == want and want[3][0] == [0, 2]
+    # ... and the crowd goes on, on both, alike: the agent in tile (0, 0) and the one added after the failure
+    for t in (mesh, single):
+        t.add_agents([(49.9, 49.9), (52.0, 50.5)], StubHighLevelPlan((0.5, 0.25)), Zanlungo(*scenes.METRIC_ZANLUNGO), 3.0)
+        for _ in range(30):
+            t.step(0.05)
+    assert mesh.read_agents().tobytes() == single.read_agents().tobytes() and len(mesh) == 4
