@@ -132,6 +132,18 @@ def cpu_baseline_openmp(agents, cell, eyesight, speed, workload="walk", budget_s
     }
 
 
+def cpu_baselines(args, per_gpu, speed):
+    """The two CPU figures of a line: the reference-shaped single-thread port (`cpu_baseline`) and, for the uniform
+    crowds, the same arithmetic on cell-sorted arrays over the host's cores (`cpu_baseline_openmp`)."""
+    uniform_kind = args.workload in ("walk", "creep")
+    wl = args.workload if uniform_kind else "creep"
+    out = {"cpu_baseline": cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)}
+    if uniform_kind:
+        # a second, stronger CPU number (not the reference's shape), for orientation
+        out["cpu_baseline_openmp"] = cpu_baseline_openmp(per_gpu, args.cell, args.eyesight, speed, workload=wl)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,9 +181,12 @@ def main():
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="hipEvent pair around the neighbour kernel at every N-th timed step (a pair costs the stream "
                          "a few us: at small crowds use a larger stride)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="--gpus > 1: CS_CFG_TILE_OVERLAP (the next step's halo exchange runs behind the border "
-                         "windows' launch on a second stream while the interior windows are stepped)")
+    ap.add_argument("--overlap", action="store_true", help="(the default for --gpus > 1 since round 5; kept for old commands)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="--gpus > 1: step WITHOUT CS_CFG_TILE_OVERLAP.  Default for N > 1 is WITH it: the next step's halo "
+                         "exchange runs behind the border windows' launch on a second stream while the interior windows "
+                         "are stepped; the other setting is timed beside it for a few steps (config.overlap_ab)")
+    ap.add_argument("--no-overlap-ab", action="store_true", help="--gpus > 1: skip the short run with the other overlap setting")
     ap.add_argument("--mesh", choices=["native", "python"], default="native",
                     help="--gpus > 1: what steps the tiles.  native (default): the C ABI's own mesh, cs_mesh_* "
                          "(csrc/cs_mesh.hip.inc; what a Rust or C++ host binds: one cs_mesh_step per step, halo records "
@@ -265,8 +280,27 @@ def main():
             progress["phase"] = phase
     ctx["arm"] = arm
 
+    args.overlap = world > 1 and not args.no_overlap
     main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
     other_leg = None
+    if world > 1 and not args.no_overlap_ab:
+        # the same crowd for a few steps with the OTHER overlap setting: one multi-GPU run says what the overlap is worth
+        line = dict(main_leg["line"]) if rank == 0 else {}
+        line["overlap_ab"] = "did not finish"
+        progress["line"] = json.dumps(line)  # (on every rank: they all leave with 0 once the headline stands)
+        arm("A/B leg (the other overlap setting)")
+        ab_steps = min(args.steps, 20)
+        ab = run_leg(args, ctx, args.scaling, ab_steps, min(args.warmup, 10), 30, headline=False, overlap=not args.overlap)
+        if rank == 0:
+            mine = {"ms_per_step": main_leg["ms_per_step"], "value": main_leg["value"], "steps": main_leg["steps"],
+                    "phase_us_max_over_ranks": main_leg["tile_report"].get("phase_us_max_over_ranks")}
+            theirs = {"ms_per_step": ab["ms_per_step"], "value": ab["value"], "steps": ab["steps"],
+                      "phase_us_max_over_ranks": ab["tile_report"].get("phase_us_max_over_ranks"),
+                      "exchanges_ahead_used": ab["tile_report"].get("exchanges_ahead_used")}
+            main_leg["line"]["config"]["overlap_ab"] = {
+                "overlap": mine if args.overlap else theirs, "no_overlap": theirs if args.overlap else mine,
+                "headline_is": "overlap" if args.overlap else "no_overlap",
+                "note": "the headline leg's figures beside a short run (its own mesh, same crowd and scaling) with the other setting"}
     if world > 1 and not args.no_second_scaling_leg:
         line = dict(main_leg["line"]) if rank == 0 else {}
         line["second_scaling_leg"] = "did not finish"
@@ -283,6 +317,16 @@ def main():
         out = main_leg["line"]
         if other_leg:
             out[other_leg["scaling"] + "_scaled"] = other_leg
+        if world > 1 and not args.no_cpu_baseline:
+            # N > 1 lines carry the CPU baseline too (review of round 4): rank 0 times the same bounded samples as at
+            # N = 1 while its peers wait at the barrier below (no GPU work is pending; a failure here loses the baseline,
+            # never the line)
+            progress["line"] = json.dumps(out)
+            arm("CPU baseline on rank 0 (the measurement is complete)")
+            try:
+                out.update(cpu_baselines(args, main_leg["per_gpu"], main_leg["speed"]))
+            except Exception as err:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": str(err)}
         print(json.dumps(out), flush=True)
     progress["line"], progress["printed"] = None, True
     arm("shutdown")
@@ -390,9 +434,11 @@ def verify_mesh(args, ctx, stepper, mesh_kind, steps_made, fill, single_engine, 
     return verdict[0]
 
 
-def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
+def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline, overlap=None):
     """One timed run of `steps` steps (after `warmup` + clock warm-up untimed ones) under `scaling`.
-    headline=True also builds the JSON line (roofline, creep leg, CPU baselines)."""
+    headline=True also builds the JSON line (roofline, creep leg, CPU baselines).  overlap: CS_CFG_TILE_OVERLAP for this
+    leg's mesh (default: args.overlap)."""
+    overlap = args.overlap if overlap is None else overlap
     torch, dist = ctx["torch"], ctx["dist"]
     rank, world, device, backend = ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
     from rmf_crowdsim_amd import Simulation, scenes, _abi
@@ -412,7 +458,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
     flags = {"auto": 0, "gather": 1, "tiled": 2}[args.kernel] | (args.debug << 8)
     if args.workload == "hotspots":
         flags |= _abi.CS_CFG_DENSE  # more than 64 neighbours in sight in the cores
-    if args.overlap and world > 1:
+    if overlap and world > 1:
         flags |= _abi.CS_CFG_TILE_OVERLAP
 
     from rmf_crowdsim_amd import LocationHash2D, Zanlungo
@@ -556,10 +602,11 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         fail(f"{leg_name}: warm-up steps", err)
     sim.profile_reset()
     # hipEvents around K4 on the engine's stream; every 4th launch of the timed region, since an
-    # event pair costs the stream ~6 us per step.  Tiles: every phase of the step by itself (pack, exchange, unpack,
-    # border / interior launch, scan, scatter), each kind with its own stride counter.
+    # event pair costs the stream ~6 us per step.  ONLY K4 inside the region the headline is taken from, at any N (round
+    # 4 timed all ten phases of a tile's step there: ten event pairs per fourth step, some spanning two streams, inside
+    # the wall clock that made the multi-GPU value); the phases get a short pass of their own after it.
     sim.profile_stride(max(1, args.profile_stride))
-    sim.profile_enable(((1 << _abi.CS_K_COUNT) - 1) if world > 1 else (1 << _abi.CS_K_NEIGHBOUR_FORCE))
+    sim.profile_enable(1 << _abi.CS_K_NEIGHBOUR_FORCE)
     arm(f"{leg_name}: timed region")
     sync_all()
     t0 = time.perf_counter()
@@ -610,8 +657,23 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
     k4 = prof["neighbour_force"]
     k4_ms = k4["total_ms"] / max(k4["launches"], 1)
     if world > 1:
-        # every phase of a tile's step, device time between hipEvents on the stream the phase ran on: rank 0's and the
-        # slowest rank's (the exchange includes the wait for the slowest peer: that is what the step pays)
+        # every phase of a tile's step (pack, exchange, unpack, border / interior launch, scan, scatter), device time
+        # between hipEvents on the stream the phase ran on, in a pass of its own OUTSIDE the headline's clock: rank 0's and
+        # the slowest rank's (the exchange includes the wait for the slowest peer: that is what the step pays)
+        arm(f"{leg_name}: per-phase pass (after the timed region)")
+        try:
+            sim.profile_reset()
+            sim.profile_stride(2)
+            sim.profile_enable((1 << _abi.CS_K_COUNT) - 1)
+            phase_steps = 24
+            for _ in range(phase_steps):
+                stepper.step(0.05, report=False)
+            steps_made += phase_steps
+            drain()
+            sim.profile_enable(0)
+            prof = sim.profile_read()
+        except Exception as err:  # noqa: BLE001
+            fail(f"{leg_name}: per-phase pass", err)
         names = list(_abi.KERNEL_NAMES)
         us = torch.tensor([1e3 * prof[k]["total_ms"] / prof[k]["launches"] if prof[k]["launches"] else 0.0 for k in names],
                           dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -619,9 +681,11 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         dist.all_reduce(us_max, op=dist.ReduceOp.MAX)
         tile_report["phase_us_rank0"] = {k: round(float(v), 2) for k, v in zip(names, us.tolist()) if v > 0}
         tile_report["phase_us_max_over_ranks"] = {k: round(float(v), 2) for k, v in zip(names, us_max.tolist()) if v > 0}
-        tile_report["phase_us_note"] = ("neighbour_force spans step_border + step_interior when the launch is split "
-                                        "(--overlap); halo_pack is absent when the step kernel packed; with --overlap the "
+        tile_report["phase_us_note"] = ("24 steps after the timed region, an event pair at every second launch of each kind; "
+                                        "neighbour_force spans step_border + step_interior when the launch is split "
+                                        "(overlap); halo_pack is absent when the step kernel packed; with the overlap the "
                                         "exchange runs on the second stream, beside step_interior")
+        tile_report["overlap"] = bool(overlap)
         if mesh_kind == "native":
             tile_report["exchange_bytes_per_step_rank0"] = stepper.exchange_bytes
             tile_report["exchanges_ahead"] = sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD)
@@ -631,7 +695,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
         tile_report["verify"] = verify_mesh(args, ctx, stepper, mesh_kind, steps_made, fill, single_engine, grid,
                                             n_total, flags)
     leg = {"value": total_agents * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "total_agents": total_agents,
-           "per_gpu": per_gpu, "steps": steps, "k4_ms": k4_ms, "tile_report": tile_report}
+           "per_gpu": per_gpu, "steps": steps, "k4_ms": k4_ms, "tile_report": tile_report, "speed": speed}
     if not headline:
         del stepper, sim
         return leg
@@ -745,7 +809,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
                 "speed": speed, "kernel": args.kernel,
                 "parallelism": "1 GPU" if world == 1 else
                 f"{tiling[0]}x{tiling[1]} spatial tiles, one per GPU, one halo exchange with the (up to) 8 neighbours over "
-                f"{backend} send/recv" + (", exchange overlapped with the interior windows" if args.overlap else ""),
+                f"{backend} send/recv" + (", exchange overlapped with the interior windows" if (overlap and world > 1) else ""),
                 "n_tti_zero": int(t_n[1].item()), "n_nonfinite": int(t_n[2].item()),
                 "n_agents_alive": alive_all,
                 "clock_warmup_steps": clock_warmup,
@@ -787,12 +851,8 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline):
             out["value_full_force"] = creep_leg["value"]
         if "random" in side_legs:
             out["scattered_scene"] = side_legs["random"]
-        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would wait for it)
-            wl = args.workload if uniform_kind else "creep"
-            out["cpu_baseline"] = cpu_baseline(per_gpu, args.cell, args.eyesight, speed, workload=wl)
-            if uniform_kind:
-                # a second, stronger CPU number (not the reference's shape), for orientation
-                out["cpu_baseline_openmp"] = cpu_baseline_openmp(per_gpu, args.cell, args.eyesight, speed, workload=wl)
+        if not args.no_cpu_baseline and world == 1:  # (N > 1: main() adds them once every leg is measured)
+            out.update(cpu_baselines(args, per_gpu, speed))
         leg["line"] = out
     return leg
 

@@ -184,6 +184,8 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_HALO_FUSE")) e->halo_fuse = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_ASYNC")) e->kTileAsync = (uint32_t)std::max(1, atoi(v));
   if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
+  if (const char* v = getenv("CS_DEBUG_CTX_BY_VALUE")) e->debug_ctx_by_value = atoi(v) != 0;  // (measurement only)
+  if (const char* v = getenv("CS_DEBUG_SORT_EVERY")) e->debug_sort_every = (uint32_t)std::max(0, atoi(v));  // (measurement only)
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_TILE_WINDOWS_CAP")) e->tile_windows_cap = (uint32_t)atoi(v);
   if (const char* v = getenv("CS_CHECK_WINDOWS")) e->check_windows = atoi(v) != 0;

@@ -65,7 +65,7 @@ def test_bench_gpus_2_steps_the_native_mesh_and_it_equals_the_single_engine():
     stepped is the C ABI's mesh (one cs_mesh_step per step), and after the timed region of either leg the whole crowd
     of the mesh equals a single engine stepped through the same scene, bit for bit (--verify)."""
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "200000", "--steps", "10", "--warmup", "3",
-                        "--clock-warmup", "5", "--no-cpu-baseline", "--verify"], env=_env(CS_BENCH_BACKEND="gloo"),
+                        "--clock-warmup", "5", "--verify"], env=_env(CS_BENCH_BACKEND="gloo"),
                        capture_output=True, text=True, timeout=900)
     line = _bench_line(p)
     assert line["n_gpus"] == 2
@@ -75,20 +75,27 @@ def test_bench_gpus_2_steps_the_native_mesh_and_it_equals_the_single_engine():
     assert cfg["agents_total"] == 200000 and cfg["agents_per_gpu"] == 100000
     assert cfg["ranks_in_comm"] == 2
     assert cfg["verify"]["mesh_equals_single_engine"] is True and cfg["verify"]["agents"] == 200000
-    # first exchange (1), clock warm-up up to 5 untimed steps in all (2), warm-up (3), timed (10), the report step (1)
-    assert cfg["verify"]["steps_compared"] == 1 + 2 + 3 + 10 + 1
+    # first exchange (1), clock warm-up up to 5 untimed steps in all (2), warm-up (3), timed (10), the report step (1),
+    # the per-phase pass outside the headline's clock (24)
+    assert cfg["verify"]["steps_compared"] == 1 + 2 + 3 + 10 + 1 + 24
     assert cfg["exchange_bytes_per_step_rank0"] > 0
     phases = cfg["phase_us_rank0"]
     assert phases["neighbour_force"] > 0 and phases["halo_unpack"] > 0 and phases["scan"] > 0 and phases["scatter"] > 0
     assert line["weak_scaled"]["agents_total"] == 400000
     assert line["weak_scaled"]["verify"]["mesh_equals_single_engine"] is True
     assert line["value"] > 0 and line["weak_scaled"]["value"] > 0
+    # round 5: the overlap is the default for N > 1, the other setting is timed beside it; N > 1 lines carry both CPU figures
+    ab = cfg["overlap_ab"]
+    assert cfg["overlap"] is True and ab["headline_is"] == "overlap"
+    assert ab["overlap"]["ms_per_step"] == line["ms_per_step"] and ab["no_overlap"]["ms_per_step"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] == "port"
+    assert line["cpu_baseline_openmp"]["value"] > line["cpu_baseline"]["value"]
 
 
 @pytest.mark.gpu
 def test_bench_gpus_2_python_mesh_for_comparison():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "100000", "--steps", "5", "--warmup", "2",
-                        "--clock-warmup", "3", "--no-cpu-baseline", "--mesh", "python", "--no-second-scaling-leg"],
+                        "--clock-warmup", "3", "--no-cpu-baseline", "--mesh", "python", "--no-second-scaling-leg", "--no-overlap-ab"],
                        env=_env(CS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     line = _bench_line(p)
     assert line["config"]["mesh"] == "python" and line["n_gpus"] == 2 and line["value"] > 0
@@ -100,7 +107,7 @@ def test_a_native_mesh_that_cannot_be_created_falls_back_to_the_python_mesh_on_e
     refused): they agree over the launcher's process group, all drop the native mesh, and the run is measured on
     the Python orchestration, saying so; with CS_BENCH_NO_FALLBACK the same failure ends the run with the phase named."""
     common = [sys.executable, BENCH, "--gpus", "2", "--agents", "60000", "--steps", "5", "--warmup", "2", "--clock-warmup", "3",
-              "--no-cpu-baseline", "--no-second-scaling-leg"]
+              "--no-cpu-baseline", "--no-second-scaling-leg", "--no-overlap-ab"]
     p = subprocess.run(common, env=_env(CS_BENCH_BACKEND="gloo", CS_BENCH_BREAK_NATIVE_MESH="1"), capture_output=True, text=True,
                        timeout=900)
     line = _bench_line(p)

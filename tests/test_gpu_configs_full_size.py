@@ -290,6 +290,38 @@ def test_config2_one_million_walkers_cross_every_cut_for_200_steps():
     assert len(cuts) == 3 and min(crossed) > 10_000
 
 
+def test_config2_split_launches_of_the_overlapped_schedule_at_full_size(monkeypatch):
+    """configs[2] under CS_CFG_TILE_OVERLAP as far as one GPU can take it through cs_mesh_*: every tile of the 4 x 2 mesh
+    steps its BORDER windows as a launch of their own, ahead of the interior ones (CS_TILE_SPLIT=1: the decomposition the
+    overlapped schedule runs on; the border launch packs the next step's halo records, the interior launch checks that
+    nobody it moved can reach the band), 1M walkers, 200 steps, 21,000 agents over each cut: the single engine's bits.
+    (The two streams and the exchange made ahead need a communicator: tests/test_gpu_tiles.py runs them on a tile of
+    configs[2]'s 125,000 agents whose peers are the rank itself; real peers need more than one GPU.)"""
+    import bench
+    from rmf_crowdsim_amd.tiles import NativeTileMesh
+    monkeypatch.setenv("CS_TILE_SPLIT", "1")
+    n, steps = 1_000_000, 200
+    pts, grid, extent, group = scenes.uniform_crowd(n, seed=7, cell_size=2.0, room=bench.walk_room(steps))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    index = LocationHash2D(**grid)
+    out = []
+    for target in (Simulation(index, flags=2, capacity_hint=n + 1024),
+                   NativeTileMesh(index, (4, 2), 1, density_per_cell=15.0, weights=pts, capacity_hint=160_000,
+                                  flags=_abi.CS_CFG_TILE_OVERLAP)):
+        scenes.add_walking_crowd(target, pts, group, lp, 2.0)
+        tile0 = target.tile(0) if isinstance(target, NativeTileMesh) else None
+        if tile0 is not None:
+            tile0.profile_stride(8)
+            tile0.profile_enable((1 << _abi.CS_K_STEP_BORDER) | (1 << _abi.CS_K_STEP_INTERIOR))
+        for k in range(steps):
+            target.step(0.05, report=False)
+        out.append(target.read_agents())
+        if tile0 is not None:  # the launches really were split
+            prof = tile0.profile_read()
+            assert prof["step_border"]["launches"] >= 20 and prof["step_interior"]["launches"] >= 20
+    assert len(out[0]) == n and out[0].tobytes() == out[1].tobytes()
+
+
 def test_config4_four_million_agents_50_steps_with_a_recut():
     """configs[4] at full size for 52 steps, the crowd walking (3.4 m: agents leave and enter the hotspots' cells and
     cross the weighted cuts), one re-cut of the running mesh at step 25.  The mesh behind the C ABI == one engine, bit
