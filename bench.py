@@ -35,7 +35,8 @@ K4_READ_BYTES = 32
 K4_WRITE_BYTES = 16
 K4_CELL_BYTES = 8
 K4_FUSED_BYTES_PER_AGENT, K4_FUSED_BYTES_PER_CELL = 60, 4
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave64 VALU instructions per second: 1024 SIMDs, one per 2 clocks
+N_SIMDS, SIMD_CLOCK_HZ = 1024, 2.4e9
+VALU_ISSUE_PEAK = N_SIMDS * SIMD_CLOCK_HZ / 2.0  # wave64 VALU instructions per second: 1024 SIMDs, one per 2 clocks
 
 
 def profile_key(workload_desc):
@@ -730,7 +731,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline, overl
     # summary taken on anything else is stale and reads as null here.
     key = profile_key(f"{args.workload} agents {per_gpu} cell {args.cell} eyesight {args.eyesight} kernel {args.kernel} "
                       f"world {world}")
-    traffic = valu_insts = None
+    traffic = valu_insts = valu_active = None
     pmc_source = None
     for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
         try:
@@ -738,6 +739,7 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline, overl
                 tr = json.load(f)
             if tr.get("profile_key") == key and not args.debug:
                 traffic, valu_insts = tr["traffic_bytes_per_launch"], tr.get("valu_wave_insts_per_launch")
+                valu_active = tr.get("valu_active_quad_cycles_per_launch")
                 pmc_source = f"profiles/{rnd}/k4_traffic.json"
                 break
         except (OSError, KeyError, ValueError):
@@ -835,6 +837,11 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline, overl
                 # the nominal one per 2 clocks per SIMD at 2.4 GHz while no measurement is cached)
                 "bound_actual": "valu_issue",
                 "valu_issue_frac": valu_frac,
+                # what the counters say about the pipe itself: SQ_ACTIVE_INST_VALU (in units of four SIMD cycles) against
+                # the kernel's duration on all 1,024 SIMDs at the 2.4 GHz peak clock: the share of cycles in which a SIMD
+                # was executing a vector instruction of ANY rate class (valu_issue_frac prices the count as if all were
+                # full rate; the gap between the two is the half- and quarter-rate instructions)
+                "valu_busy_frac": (valu_active * 4.0 / (N_SIMDS * k4_ms * 1e-3 * SIMD_CLOCK_HZ)) if (valu_active and k4_ms > 0) else None,
                 "valu_wave_insts_per_launch": valu_insts,
                 "valu_issue_peak_per_s": valu_peak,
                 "valu_ceiling": ceiling,

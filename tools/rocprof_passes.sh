@@ -44,6 +44,7 @@ summary={"command": "python bench.py $args (rocprofv3 --pmc, separate passes; to
          "traffic_bytes_per_launch": int((2.0*fetch+write)*1024) if fetch and write else None,
          "valu_wave_insts_per_launch": k4.get("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": k4.get("SQ_INSTS_SALU"),
          "lds_wave_insts_per_launch": k4.get("SQ_INSTS_LDS"), "wave_quad_cycles_per_launch": k4.get("SQ_WAVE_CYCLES"),
+         "valu_active_quad_cycles_per_launch": k4.get("SQ_ACTIVE_INST_VALU"),
          "lds_bank_conflict_cycles_per_launch": k4.get("SQ_LDS_BANK_CONFLICT"),
          "kernel_ms_in_this_run": line["roofline"]["kernel_ms"]}
 json.dump(summary, open(out+"/k4_traffic.json","w"), indent=1)
