@@ -541,7 +541,8 @@ def _rank_nccl_single(port, out_path):
         # records; everything else of the overlapped schedule runs at full size and must give the plain schedule's bits.
         def middle_tile_125k(flags):
             with torch.cuda.stream(side):
-                big = dict(width=420.0, height=240.0, cell_size=2.0, offset=(0.0, 0.0))  # (the row stride is width / cell: x is the long side)
+                # (location_hash_2d.rs:59: x rows are bounded by HEIGHT / cell, the y stride is WIDTH / cell)
+                big = dict(width=240.0, height=420.0, cell_size=2.0, offset=(0.0, 0.0))
                 sim = Simulation(LocationHash2D(**big), device=0, stream=side.cuda_stream, tile=(10, 200, 0, 120),
                                  halo_cells=1, flags=flags, capacity_hint=140_000)
                 cap = 8192

@@ -1,8 +1,10 @@
 """Round 5, the one structural K4 experiment: what would a sort kept for k steps save at most?
 
 CS_DEBUG_SORT_EVERY=k (measurement only, cs_engine::rebuild) skips the scan and the scatter + window builder on k - 1 of k
-steps.  That is correct only while no agent changes its cell, which holds in the creep scene (1 mm/s): the bits must
-equal the plain run's, and do, or this script fails.  The time saved is the UPPER BOUND of the sort's share of what a
+steps.  That is correct only while no agent changes its cell: the creep scene slowed to 1e-9 m/s (nobody of a million
+comes within the 1.5e-8 m it travels of a cell boundary; at the bench's 2.5e-4 m/s thousands do, and the lever then
+steps garbage); the kernels' cost does not depend on the speed scale.  The bits must equal the plain run's, or this
+script fails.  The time saved is the UPPER BOUND of the sort's share of what a
 Verlet-style scheme (sort and candidate lists with a skin, reused for k steps) could gain; the filter's share is bounded
 by the ablation of profiles/K4_LEVERS.md (the candidates' part of the kernel).  Run on the GPU box:
     python tools/sort_every_bench.py > gpurun_out/sort_every.txt
@@ -23,7 +25,7 @@ def run(k, agents, steps, workload="creep"):
         os.environ["CS_DEBUG_SORT_EVERY"] = str(k)
     else:
         os.environ.pop("CS_DEBUG_SORT_EVERY", None)
-    speed = min(scenes.CREEP_SPEED, 0.25 / (steps + 100))
+    speed = 1e-9
     sim, grid, extent = bench.build_crowd(Simulation, agents, 2.0, 2.0, speed, workload=workload, steps=steps + 100,
                                           capacity=agents + 1024)
     for _ in range(80):
