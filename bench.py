@@ -244,17 +244,34 @@ def main():
         args.scaling = "strong"
     ctx = dict(torch=torch, dist=dist, rank=rank, world=world, device=device, backend=backend)
 
+    progress = {"phase": "start", "line": None}
+
     def fail(phase, err):
         """A rank that cannot go on says in which phase and leaves at once with a non-zero code (no unwinding through
-        collectives its peers are not in; the launcher ends the other ranks)."""
+        collectives its peers are not in; the launcher ends the other ranks).  If a complete line already stands (the
+        short leg without the overlap, measured before the overlapped headline leg), rank 0 prints it first: code 4."""
         print(f"bench: rank {rank} FAILED in phase '{phase}': {err}", file=sys.stderr, flush=True)
+        if progress["line"] is not None:
+            if rank == 0:
+                print(progress["line"], flush=True)
+            os._exit(4)
         os._exit(5)
     ctx["fail"] = fail
+    if world > 1 and rank == 0:
+        # the launcher ends the other ranks with SIGTERM when one of them fails: rank 0 still says what it has
+        import signal
+
+        def on_term(_sig, _frame):
+            if progress["line"] is not None:
+                print(progress["line"], flush=True)
+                os._exit(4)
+            os._exit(5)
+        signal.signal(signal.SIGTERM, on_term)
 
     # N > 1: the first run of this code over RCCL with real peers may be the driver's.  A rank that sits in one
     # phase for --watchdog seconds says where and leaves; if the headline leg is already measured (the stall is in
     # the optional second leg), rank 0 prints its line first, so the measurement is not lost with the extra.
-    progress = {"phase": "headline leg (" + args.scaling + " scaling)", "line": None}
+    progress["phase"] = "headline leg (" + args.scaling + " scaling)"
     watchdog = None
     if world > 1 and args.watchdog > 0:
         import threading
@@ -282,26 +299,35 @@ def main():
     ctx["arm"] = arm
 
     args.overlap = world > 1 and not args.no_overlap
+    ab = None
+    if world > 1 and not args.no_overlap_ab:
+        # The same crowd for a few steps with the OTHER overlap setting, so that one multi-GPU run says what the overlap is
+        # worth.  When the headline is the overlapped schedule (the default), which has never run with real peers, this
+        # leg runs FIRST and its complete line stands as the fallback: a headline leg that fails or hangs then costs the
+        # A/B, not the measurement (exit code 4, "fallback" in the line).
+        arm("A/B leg (the other overlap setting)")
+        ab = run_leg(args, ctx, args.scaling, min(args.steps, 20), min(args.warmup, 10), 30, headline=args.overlap,
+                     overlap=not args.overlap)
+        if args.overlap:
+            line = dict(ab["line"]) if rank == 0 else {}
+            line["fallback"] = ("the overlapped headline leg did not finish: this is the short leg WITHOUT the overlap "
+                                "that ran before it")
+            progress["line"] = json.dumps(line)
+        arm("headline leg (" + args.scaling + " scaling)")
     main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
     other_leg = None
-    if world > 1 and not args.no_overlap_ab:
-        # the same crowd for a few steps with the OTHER overlap setting: one multi-GPU run says what the overlap is worth
-        line = dict(main_leg["line"]) if rank == 0 else {}
-        line["overlap_ab"] = "did not finish"
-        progress["line"] = json.dumps(line)  # (on every rank: they all leave with 0 once the headline stands)
-        arm("A/B leg (the other overlap setting)")
-        ab_steps = min(args.steps, 20)
-        ab = run_leg(args, ctx, args.scaling, ab_steps, min(args.warmup, 10), 30, headline=False, overlap=not args.overlap)
-        if rank == 0:
-            mine = {"ms_per_step": main_leg["ms_per_step"], "value": main_leg["value"], "steps": main_leg["steps"],
-                    "phase_us_max_over_ranks": main_leg["tile_report"].get("phase_us_max_over_ranks")}
-            theirs = {"ms_per_step": ab["ms_per_step"], "value": ab["value"], "steps": ab["steps"],
-                      "phase_us_max_over_ranks": ab["tile_report"].get("phase_us_max_over_ranks"),
-                      "exchanges_ahead_used": ab["tile_report"].get("exchanges_ahead_used")}
-            main_leg["line"]["config"]["overlap_ab"] = {
-                "overlap": mine if args.overlap else theirs, "no_overlap": theirs if args.overlap else mine,
-                "headline_is": "overlap" if args.overlap else "no_overlap",
-                "note": "the headline leg's figures beside a short run (its own mesh, same crowd and scaling) with the other setting"}
+    if ab is not None and rank == 0:
+        mine = {"ms_per_step": main_leg["ms_per_step"], "value": main_leg["value"], "steps": main_leg["steps"],
+                "phase_us_max_over_ranks": main_leg["tile_report"].get("phase_us_max_over_ranks"),
+                "exchanges_ahead_used": main_leg["tile_report"].get("exchanges_ahead_used")}
+        theirs = {"ms_per_step": ab["ms_per_step"], "value": ab["value"], "steps": ab["steps"],
+                  "phase_us_max_over_ranks": ab["tile_report"].get("phase_us_max_over_ranks"),
+                  "exchanges_ahead_used": ab["tile_report"].get("exchanges_ahead_used")}
+        main_leg["line"]["config"]["overlap_ab"] = {
+            "overlap": mine if args.overlap else theirs, "no_overlap": theirs if args.overlap else mine,
+            "headline_is": "overlap" if args.overlap else "no_overlap",
+            "note": "the headline leg's figures beside a short run (its own mesh, same crowd and scaling) with the other "
+                    "setting" + (", which ran first" if args.overlap else "")}
     if world > 1 and not args.no_second_scaling_leg:
         line = dict(main_leg["line"]) if rank == 0 else {}
         line["second_scaling_leg"] = "did not finish"
