@@ -582,13 +582,18 @@ def test_crossing_flows_at_walking_speed_300_steps():
     pref_by_id = np.concatenate([pref[group == 0], pref[group == 1]])
     assert ids0[0] == 0 and ids1[-1] == n - 1
     xy, vel = by_id.copy(), None
+    xy32, vel32 = by_id.copy(), None   # the f32 build of the same CPU path (per-cell positions, underflow guard): round 5
     struck = np.zeros(n, dtype=np.uint8)
-    worst = worst_dv = worst_tail = dodging = 0.0
+    worst = worst_dv = worst_tail = dodging = worst32 = 0.0
     beyond = 0
     strongest = []
     for chunk in range(steps // 50):
         xy, vel, sec = fast_steps(xy, pref_by_id, CROSSING_ZANLUNGO, 2.0, grid, 0.05, 50, threads=8, vel=vel, spurious=struck)
         assert sec >= 0 and np.isfinite(xy).all() and np.isfinite(vel).all() and not struck.any()  # the scene is certified
+        xy32, vel32, sec32 = fast_steps(xy32, pref_by_id, CROSSING_ZANLUNGO, 2.0, grid, 0.05, 50, threads=8, vel=vel32,
+                                        kind="f32", guarded=True, cell_relative=True)
+        assert sec32 >= 0
+        worst32 = max(worst32, float((np.hypot(*(xy32 - xy).T) / extent).max()))
         for sim in runs.values():
             for _ in range(49):
                 sim.step(0.05, report=False)
@@ -612,7 +617,12 @@ def test_crossing_flows_at_walking_speed_300_steps():
     # A dodge is a discontinuity of the model (a neighbour enters the eyesight, a grazing pair's discriminant changes
     # sign): an agent whose f32 and f64 copies take such a decision one step apart ends up centimetres away (one of
     # these 4,000 does: 1.0e-4 of L).  p99.9 stays within 1e-5 of L, at most three agents go beyond that, nobody beyond 1e-3.
-    assert worst_tail <= 1e-5 and worst <= 1e-3 and beyond <= 3
+    # Round 5: the f32 build of the CPU path (an independent implementation of the engine's precision class) beside it.  On
+    # THIS draw it has no flip at all (worst agent 1.1e-6) where the engine has its one; at configs[1]'s size and the full
+    # horizon the two have 13 and 19 such agents in 100,000 (tests/test_gpu_north_star.py): the rate of flips is the
+    # scene's, which agents flip is the arithmetic's.  The flat bound on the worst agent is 3e-4 (was 1e-3).
+    print(f"worst agent: engine {worst:.2e}, f32 leg of the CPU path {worst32:.2e}")
+    assert worst_tail <= 1e-5 and beyond <= 3 and worst <= 3e-4 and worst32 <= 3e-4
     assert worst_dv <= 2e-3
 
 
