@@ -1125,6 +1125,11 @@ int cs_allreduce_max_i32_rccl(cs_engine* e, int* values_dev, size_t n) {
     return 8;
   }
   if (n == 0) return 0;
+  // Every operation on the communicator is ordered against every other ON EVERY RANK ALIKE: an exchange made ahead on the
+  // second stream (CS_CFG_TILE_OVERLAP) comes first, then this (the engine's stream waits for its event; a no-op when
+  // none was made).  Two operations of one communicator in flight on two streams in an order that differs between
+  // ranks is a deadlock RCCL does not report.
+  if (e->aux_stream && e->ev_xchg && hipStreamWaitEvent(e->stream, e->ev_xchg, 0) != hipSuccess) return 90;
   return rccl_api::ok(e, a.all_reduce(values_dev, values_dev, n, rccl_api::kInt32, rccl_api::kMax, e->rccl_comm, e->stream),
                       "ncclAllReduce") ? 0 : 8;
 }
