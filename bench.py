@@ -182,11 +182,13 @@ def main():
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="hipEvent pair around the neighbour kernel at every N-th timed step (a pair costs the stream "
                          "a few us: at small crowds use a larger stride)")
-    ap.add_argument("--overlap", action="store_true", help="(the default for --gpus > 1 since round 5; kept for old commands)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="--gpus > 1: step WITHOUT CS_CFG_TILE_OVERLAP.  Default for N > 1 is WITH it: the next step's halo "
-                         "exchange runs behind the border windows' launch on a second stream while the interior windows "
-                         "are stepped; the other setting is timed beside it for a few steps (config.overlap_ab)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="--gpus > 1: the headline leg steps WITH CS_CFG_TILE_OVERLAP (the next step's halo exchange runs "
+                         "behind the border windows' launch on a second stream while the interior windows are stepped).  "
+                         "Not the default: on one GPU with RCCL self-peers the split launch costs more than the exchange it "
+                         "hides (round 5, profiles/r05/overlap_ab_one_gpu.txt); whichever setting is the headline, the OTHER "
+                         "one is timed beside it for 20 steps (config.overlap_ab), so one multi-GPU run measures both")
+    ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for old commands)")
     ap.add_argument("--no-overlap-ab", action="store_true", help="--gpus > 1: skip the short run with the other overlap setting")
     ap.add_argument("--mesh", choices=["native", "python"], default="native",
                     help="--gpus > 1: what steps the tiles.  native (default): the C ABI's own mesh, cs_mesh_* "
@@ -284,50 +286,38 @@ def main():
             # 3: nothing measured; 4: the headline line stands (printed above or before), an extra leg or the shutdown hung
             os._exit(4 if (progress["line"] is not None or progress.get("printed")) else 3)
 
-        def arm(phase):
+        def arm(phase, seconds=None):
             nonlocal watchdog
             if watchdog is not None:
                 watchdog.cancel()
             progress["phase"] = phase
-            watchdog = threading.Timer(args.watchdog, expired)
+            watchdog = threading.Timer(min(args.watchdog, seconds or args.watchdog), expired)
             watchdog.daemon = True
             watchdog.start()
         arm(progress["phase"])
     else:
-        def arm(phase):
+        def arm(phase, seconds=None):
             progress["phase"] = phase
     ctx["arm"] = arm
 
-    args.overlap = world > 1 and not args.no_overlap
+    args.overlap = world > 1 and args.overlap and not args.no_overlap
     ab = None
-    if world > 1 and not args.no_overlap_ab:
-        # The same crowd for a few steps with the OTHER overlap setting, so that one multi-GPU run says what the overlap is
-        # worth.  When the headline is the overlapped schedule (the default), which has never run with real peers, this
-        # leg runs FIRST and its complete line stands as the fallback: a headline leg that fails or hangs then costs the
-        # A/B, not the measurement (exit code 4, "fallback" in the line).
-        arm("A/B leg (the other overlap setting)")
-        ab = run_leg(args, ctx, args.scaling, min(args.steps, 20), min(args.warmup, 10), 30, headline=args.overlap,
-                     overlap=not args.overlap)
-        if args.overlap:
-            line = dict(ab["line"]) if rank == 0 else {}
-            line["fallback"] = ("the overlapped headline leg did not finish: this is the short leg WITHOUT the overlap "
-                                "that ran before it")
-            progress["line"] = json.dumps(line)
+
+    def overlap_ab_leg(headline):
+        arm("A/B leg (the other overlap setting)", 180.0)
+        return run_leg(args, ctx, args.scaling, min(args.steps, 20), min(args.warmup, 10), 30, headline=headline,
+                       overlap=not args.overlap)
+    if world > 1 and not args.no_overlap_ab and args.overlap:
+        # The overlapped schedule has never run with real peers: when it is asked for as the headline, the short leg
+        # WITHOUT it runs first and its complete line stands as the fallback (a headline leg that fails or hangs then costs
+        # the A/B, not the measurement: exit code 4, "fallback" in the line).
+        ab = overlap_ab_leg(True)
+        line = dict(ab["line"]) if rank == 0 else {}
+        line["fallback"] = "the overlapped headline leg did not finish: this is the short leg WITHOUT the overlap that ran before it"
+        progress["line"] = json.dumps(line)
         arm("headline leg (" + args.scaling + " scaling)")
     main_leg = run_leg(args, ctx, args.scaling, args.steps, args.warmup, args.clock_warmup, headline=True)
     other_leg = None
-    if ab is not None and rank == 0:
-        mine = {"ms_per_step": main_leg["ms_per_step"], "value": main_leg["value"], "steps": main_leg["steps"],
-                "phase_us_max_over_ranks": main_leg["tile_report"].get("phase_us_max_over_ranks"),
-                "exchanges_ahead_used": main_leg["tile_report"].get("exchanges_ahead_used")}
-        theirs = {"ms_per_step": ab["ms_per_step"], "value": ab["value"], "steps": ab["steps"],
-                  "phase_us_max_over_ranks": ab["tile_report"].get("phase_us_max_over_ranks"),
-                  "exchanges_ahead_used": ab["tile_report"].get("exchanges_ahead_used")}
-        main_leg["line"]["config"]["overlap_ab"] = {
-            "overlap": mine if args.overlap else theirs, "no_overlap": theirs if args.overlap else mine,
-            "headline_is": "overlap" if args.overlap else "no_overlap",
-            "note": "the headline leg's figures beside a short run (its own mesh, same crowd and scaling) with the other "
-                    "setting" + (", which ran first" if args.overlap else "")}
     if world > 1 and not args.no_second_scaling_leg:
         line = dict(main_leg["line"]) if rank == 0 else {}
         line["second_scaling_leg"] = "did not finish"
@@ -340,6 +330,27 @@ def main():
                      "agents_total": leg["total_agents"], "agents_per_gpu": leg["per_gpu"], "steps": leg["steps"],
                      "kernel_ms": leg["k4_ms"], **leg["tile_report"]}
 
+    if world > 1 and not args.no_overlap_ab and not args.overlap:
+        # the default: the headline stands; the same crowd for 20 steps under the overlapped schedule beside it
+        # (LAST of the legs, under a shorter watchdog: it is the one schedule that has never met real peers)
+        line = dict(main_leg["line"]) if rank == 0 else {}
+        if other_leg:
+            line[other_leg["scaling"] + "_scaled"] = other_leg
+        line["overlap_ab"] = "did not finish"
+        progress["line"] = json.dumps(line)  # (on every rank: they all leave with 0 once the headline stands)
+        ab = overlap_ab_leg(False)
+    if ab is not None and rank == 0:
+        mine = {"ms_per_step": main_leg["ms_per_step"], "value": main_leg["value"], "steps": main_leg["steps"],
+                "phase_us_max_over_ranks": main_leg["tile_report"].get("phase_us_max_over_ranks"),
+                "exchanges_ahead_used": main_leg["tile_report"].get("exchanges_ahead_used")}
+        theirs = {"ms_per_step": ab["ms_per_step"], "value": ab["value"], "steps": ab["steps"],
+                  "phase_us_max_over_ranks": ab["tile_report"].get("phase_us_max_over_ranks"),
+                  "exchanges_ahead_used": ab["tile_report"].get("exchanges_ahead_used")}
+        main_leg["line"]["config"]["overlap_ab"] = {
+            "overlap": mine if args.overlap else theirs, "no_overlap": theirs if args.overlap else mine,
+            "headline_is": "overlap" if args.overlap else "no_overlap",
+            "note": "the headline leg's figures beside a short run (its own mesh, same crowd and scaling) with the other "
+                    "setting" + (", which ran first" if args.overlap else ", which ran after it")}
     if rank == 0:
         out = main_leg["line"]
         if other_leg:

@@ -84,12 +84,27 @@ def test_bench_gpus_2_steps_the_native_mesh_and_it_equals_the_single_engine():
     assert line["weak_scaled"]["agents_total"] == 400000
     assert line["weak_scaled"]["verify"]["mesh_equals_single_engine"] is True
     assert line["value"] > 0 and line["weak_scaled"]["value"] > 0
-    # round 5: the overlap is the default for N > 1, the other setting is timed beside it; N > 1 lines carry both CPU figures
+    # round 5: the overlapped schedule is timed beside the headline for 20 steps (last of the legs); N > 1 lines carry both
+    # CPU figures
     ab = cfg["overlap_ab"]
-    assert cfg["overlap"] is True and ab["headline_is"] == "overlap"
-    assert ab["overlap"]["ms_per_step"] == line["ms_per_step"] and ab["no_overlap"]["ms_per_step"] > 0
+    assert cfg["overlap"] is False and ab["headline_is"] == "no_overlap"
+    assert ab["no_overlap"]["ms_per_step"] == line["ms_per_step"] and ab["overlap"]["ms_per_step"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] == "port"
     assert line["cpu_baseline_openmp"]["value"] > line["cpu_baseline"]["value"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_with_the_overlap_as_the_headline_runs_the_plain_leg_first():
+    """--overlap: the schedule that has never met real peers is the headline only behind a complete fallback line (the
+    short leg without it runs first); when it finishes, the line is its own and carries both."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "100000", "--steps", "5", "--warmup", "2",
+                        "--clock-warmup", "3", "--no-cpu-baseline", "--no-second-scaling-leg", "--overlap"],
+                       env=_env(CS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    line = _bench_line(p)
+    ab = line["config"]["overlap_ab"]
+    assert "fallback" not in line and line["config"]["overlap"] is True and ab["headline_is"] == "overlap"
+    assert ab["overlap"]["ms_per_step"] == line["ms_per_step"] and ab["no_overlap"]["ms_per_step"] > 0
+    assert "ran first" in ab["note"]
 
 
 @pytest.mark.gpu

@@ -20,6 +20,7 @@ def main():
     torch.cuda.set_device(0)
     side = torch.cuda.Stream()
     steps = 400
+    print("(the phase lines come before the summary line of each pair: plain first, overlapped second)")
 
     def run(flags, n=125_000, columns=560):
         with torch.cuda.stream(side):
@@ -47,6 +48,19 @@ def main():
                 sim.tile_step_rccl(0.05)
             side.synchronize()
             el = time.perf_counter() - t0
+            # the phases, in a pass of their own (event pairs cost the streams a few us each)
+            sim.profile_reset()
+            sim.profile_stride(2)
+            sim.profile_enable((1 << _abi.CS_K_COUNT) - 1)
+            for _ in range(40):
+                sim.tile_step_rccl(0.05)
+            side.synchronize()
+            sim.profile_enable(0)
+            prof = sim.profile_read()
+            print("   phases (us):", {k: round(1e3 * v["total_ms"] / v["launches"], 1) for k, v in prof.items() if v["launches"]}, flush=True)
+            for _ in range(steps - 40):
+                sim.tile_step_rccl(0.05)
+            side.synchronize()
             out = sim.read_agents()
             stats = (sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD), sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD_USED))
             del sim
