@@ -1176,8 +1176,6 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
   if (rc == 0) e->steps_done += 1;
   if (rc == 0 && e->border_on_aux && e->halo_prepacked) {
     e->border_on_aux = false;
-    // the border windows (on the engine's stream) have packed: the exchange follows THEM, beside the interior windows
-    HIP_OK_E(e, hipStreamWaitEvent(e->aux_stream, e->ev_border, 0));
     if (int rc2 = halo_exchange_rccl_on(e, -1, e->aux_stream)) return rc2;
     HIP_OK_E(e, hipEventRecord(e->ev_xchg, e->aux_stream));
     e->exchanged_ahead = true;
