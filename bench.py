@@ -87,7 +87,7 @@ def cpu_baseline(agents, cell, eyesight, speed, workload="walk", budget_s=15.0):
     same workload: same density / parameters, fewer agents, a few steps."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_sim import OracleSimulation
-    n = min(agents, 100_000)
+    n = min(agents, 1_000_000)  # (round 5: at the metric's own 1M agents; until then a 100k sample was extrapolated)
     sim, _, _ = build_crowd(OracleSimulation, n, cell, eyesight, speed, workload=workload, steps=110)
     sim.step(0.05)  # first step: all velocities 0 -> no forces; not representative
     steps, t0 = 0, time.perf_counter()
@@ -99,10 +99,9 @@ def cpu_baseline(agents, cell, eyesight, speed, workload="walk", budget_s=15.0):
             break
     return {
         "value": n * steps / el, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{n} agents x {steps} steps of the same scene (density, planner, eyesight, dt), "
-                  f"oracle/crowdstep_oracle.cpp f64 single thread, {el:.1f} s; sampled at {n} agents because the port "
-                  f"takes ~3 us per agent-step (1M agents: 3 s per step, and minutes to fill its hash maps) and its "
-                  f"rate does not improve with the population (hash-map bound: the larger crowd only misses cache more)",
+        "sample": f"{n} agents x {steps} steps of the same scene (density, planner, eyesight, dt) after one untimed step, "
+                  f"oracle/crowdstep_oracle.cpp (the reference's data structures: hash maps, per-cell sets) f64 single "
+                  f"thread, {el:.1f} s",
     }
 
 
@@ -362,7 +361,7 @@ def main():
             progress["line"] = json.dumps(out)
             arm("CPU baseline on rank 0 (the measurement is complete)")
             try:
-                out.update(cpu_baselines(args, main_leg["per_gpu"], main_leg["speed"]))
+                out.update(cpu_baselines(args, main_leg["total_agents"], main_leg["speed"]))  # (the whole crowd: the metric's 1M agents)
             except Exception as err:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": str(err)}
         print(json.dumps(out), flush=True)

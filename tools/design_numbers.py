@@ -99,7 +99,7 @@ a = row("stream_route")
 L.append(f"| the same stream with device route followers (`--planner route`) | {a[0]:.3f} | {g(a[1])} | {a[2] * 1e3:.1f} us | {was('stream_route')} |")
 a = row("readback")
 L.append(f"| a frame of all agents to pinned host memory every step (`--readback`) | {a[0]:.2f} | {g(a[1])} ({a[1] * 32 / 1e9:.0f} GB/s over PCIe) | — | {was('readback')} |")
-L.append(f"| CPU baseline: oracle port, f64, 1 thread, default scene at 100k agents | — | {g(d['cpu_baseline']['value'])} | | |")
+L.append(f"| CPU baseline (`cpu_baseline`): the reference-shaped oracle port, f64, 1 thread, default scene, {d['cpu_baseline']['sample'].split(' of ')[0]} | — | {g(d['cpu_baseline']['value'])} | | at 100k agents: 3.5e5 |")
 L.append(f"| CPU, the same arithmetic on cell-sorted arrays with OpenMP (16 threads, 1M agents; not the reference's shape) | — | {g(d['cpu_baseline_openmp']['value'])} | | |")
 L.append("")
 scan = stats.get("k_scan_onepass")
