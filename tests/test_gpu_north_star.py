@@ -173,6 +173,45 @@ def test_the_headline_workload_at_one_million_agents_for_1000_steps(workload):
         assert np.mean(force > 0) > 0.9
 
 
+def test_the_scattered_crowd_at_configs1_size_for_1000_steps_three_ways():
+    """The third scene bench.py times (`scattered_scene`: a randomly thinned lattice, neighbour counts that scatter like a
+    real crowd's, forces of every size the creep leaves) at configs[1]'s 100,000 agents for the north star's 1000 steps:
+    engine / f32 leg of the CPU path / f64 CPU path.  The reference's f64 path is struck by its own underflow flaw far
+    more often here than on the lattice (neighbours at every distance: ~760 agents of 100,000); they are named by the
+    CPU side and left out, nobody else."""
+    n, steps = 100_000, 1000
+    pts, grid, extent, group = scenes.random_crowd(n, seed=7, cell_size=2.0)
+    speed = min(scenes.CREEP_SPEED, 0.25 / (steps + 2))
+    lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+    sim = Simulation(LocationHash2D(**grid))
+    ids = np.asarray(scenes.add_counterflow(sim, pts, group, speed, lp, 2.0))
+    for k in range(steps - 1):
+        sim.step(0.05, report=False)
+    sim.step(0.05)
+    assert sim.last_report["n_tti_zero"] == 0 and sim.last_report["n_nonfinite"] == 0 and sim.last_report["n_agents"] == n
+    a = sim.read_agents()
+    by_id = np.empty_like(pts)
+    by_id[ids] = pts
+    pref = np.zeros_like(pts)
+    pref[ids, 1] = np.where(group == 0, speed, -speed)
+    struck = np.zeros(n, dtype=np.uint8)
+    x64, v64, sec = fast_steps(by_id, pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, steps, threads=THREADS, spurious=struck)
+    x32, _, sec32 = fast_steps(by_id, pref, scenes.METRIC_ZANLUNGO, 2.0, grid, 0.05, steps, threads=THREADS, kind="f32",
+                               guarded=True, cell_relative=True)
+    assert sec > 0 and sec32 > 0 and np.isfinite(x32).all() and np.isfinite(a["x"]).all()
+    ok = np.isfinite(x64).all(axis=1)
+    assert ((~ok) == (struck != 0)).all() and (~ok).sum() <= 3000
+    d_e64 = _dist(a, x64, extent)[ok]
+    d_3264 = (np.hypot(*(x32 - x64).T) / extent)[ok]
+    d_e32 = _dist(a, x32, extent)
+    force = np.hypot(v64[ok, 0] - pref[ok, 0], v64[ok, 1] - pref[ok, 1])
+    print(f"scattered crowd 100k x 1000 steps: {int((~ok).sum())} agents NaN on the reference's f64 path; forced "
+          f"{float(np.mean(force > 0)):.3f}\n   engine vs f64: {_summary(d_e64)}\n   f32    vs f64: {_summary(d_3264)}\n"
+          f"   engine vs f32: {_summary(d_e32)}")
+    assert d_e64.max() <= 1e-4 and np.mean(force > 0) > 0.7
+    assert d_e64.max() <= 10.0 * max(d_3264.max(), 1e-7)  # the same order as the other f32 implementation
+
+
 def test_config4_four_million_hotspot_agents_against_the_f64_path():
     """configs[4] at full size against the f64 CPU path (round 4 checked it through properties only): 4M agents, half of
     them in Gaussian hotspots of up to 4.9 agents / m^2 (neighbour lists beyond 64 entries: CS_CFG_DENSE, windows walked
