@@ -22,12 +22,23 @@ def main():
     steps = 400
     print("(the phase lines come before the summary line of each pair: plain first, overlapped second)")
 
-    def run(flags, n=125_000, columns=560):
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
+    # the tile: x rows [10, rows_x) of a grid whose x extent is its HEIGHT (location_hash_2d.rs:59), all of y; the crowd
+    # keeps 6 m clear of the XLO / XHI edges (their bands are 4 m deep)
+    columns = 560 if n == 125_000 else int(np.ceil(np.sqrt(n)))
+    rows = int(np.ceil(n / columns))
+    x_extent, y_extent = columns * 0.6325, rows * 0.6325
+    tile_x1 = int(np.ceil((26.0 + x_extent + 6.0) / 2.0))
+    grid_h = 2.0 * (tile_x1 + 10)
+    grid_w = 2.0 * int(np.ceil((10.0 + y_extent + 80.0) / 2.0))
+
+    def run(flags):
         with torch.cuda.stream(side):
-            big = dict(width=240.0, height=420.0, cell_size=2.0, offset=(0.0, 0.0))
-            sim = Simulation(LocationHash2D(**big), device=0, stream=side.cuda_stream, tile=(10, 200, 0, 120),
-                             halo_cells=1, flags=flags, capacity_hint=140_000)
-            cap = 8192
+            big = dict(width=max(grid_w, 240.0), height=max(grid_h, 420.0), cell_size=2.0, offset=(0.0, 0.0))
+            sim = Simulation(LocationHash2D(**big), device=0, stream=side.cuda_stream,
+                             tile=(10, tile_x1, 0, int(big["width"] / 2.0)), halo_cells=1, flags=flags,
+                             capacity_hint=n + n // 8)
+            cap = max(8192, int(2 * 4.0 * y_extent * 2.5 * 1.5))
             keep = {d: (torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda"),
                         torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda")) for d in (XLO, XHI)}
             for d, (s_, r_) in keep.items():
@@ -69,7 +80,7 @@ def main():
     for rep in range(2):
         plain, us_plain, _ = run(0)
         ahead, us_ahead, stats = run(_abi.CS_CFG_TILE_OVERLAP)
-        print(f"125,000 agents on a middle tile, 2 self-peers over RCCL, {steps} steps: plain {us_plain:.1f} us/step, "
+        print(f"{n} agents on a middle tile, 2 self-peers over RCCL, {steps} steps: plain {us_plain:.1f} us/step, "
               f"overlapped {us_ahead:.1f} us/step (exchanges ahead / used {stats}), same bits {plain.tobytes() == ahead.tobytes()}",
               flush=True)
 
