@@ -184,6 +184,7 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (const char* v = getenv("CS_HALO_FUSE")) e->halo_fuse = atoi(v) != 0;
   if (const char* v = getenv("CS_TILE_ASYNC")) e->kTileAsync = (uint32_t)std::max(1, atoi(v));
   if (const char* v = getenv("CS_TILE_SPLIT")) e->tile_split_force = atoi(v) != 0;
+  if (const char* v = getenv("CS_OVERLAP_MODE")) e->overlap_early = v[0] != 's';  // "split": rounds 2-4's two launches
   if (const char* v = getenv("CS_DEBUG_CTX_BY_VALUE")) e->debug_ctx_by_value = atoi(v) != 0;  // (measurement only)
   if (const char* v = getenv("CS_DEBUG_SORT_EVERY")) e->debug_sort_every = (uint32_t)std::max(0, atoi(v));  // (measurement only)
   if (const char* v = getenv("CS_TILE_STAGE_CAP")) e->tile_stage_cap = (uint32_t)atoi(v);
@@ -1176,6 +1177,10 @@ int cs_tile_step_rccl(cs_engine* e, double dt_seconds, cs_step_report* report) {
   if (rc == 0) e->steps_done += 1;
   if (rc == 0 && e->border_on_aux && e->halo_prepacked) {
     e->border_on_aux = false;
+    if (e->early_pending) {  // (the border windows are the first workgroups of the ONE launch: wait for the last of them)
+      e->early_pending = false;
+      hipLaunchKernelGGL(k_wait_border, dim3(1), dim3(64), 0, e->aux_stream, e->ctr, e->early_seq);
+    }
     if (int rc2 = halo_exchange_rccl_on(e, -1, e->aux_stream)) return rc2;
     HIP_OK_E(e, hipEventRecord(e->ev_xchg, e->aux_stream));
     e->exchanged_ahead = true;
