@@ -19,6 +19,7 @@ def main():
     from rmf_crowdsim_amd.tiles import RECORD, XHI, XLO
     torch.cuda.set_device(0)
     side = torch.cuda.Stream()
+    own = os.environ.get("CS_TOOL_OWN_STREAM") == "1"  # the engine creates its own stream (CS_RESERVE_CUS applies to that one)
     steps = 400
     print("(the phase lines come before the summary line of each pair: plain first, overlapped second)")
 
@@ -35,12 +36,13 @@ def main():
     def run(flags):
         with torch.cuda.stream(side):
             big = dict(width=max(grid_w, 240.0), height=max(grid_h, 420.0), cell_size=2.0, offset=(0.0, 0.0))
-            sim = Simulation(LocationHash2D(**big), device=0, stream=side.cuda_stream,
+            sim = Simulation(LocationHash2D(**big), device=0, stream=None if own else side.cuda_stream,
                              tile=(10, tile_x1, 0, int(big["width"] / 2.0)), halo_cells=1, flags=flags,
                              capacity_hint=n + n // 8)
             cap = max(8192, int(2 * 4.0 * y_extent * 2.5 * 1.5))
             keep = {d: (torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda"),
                         torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda")) for d in (XLO, XHI)}
+            torch.cuda.synchronize()  # (the buffers were zeroed on torch's stream; the engine may have its own)
             for d, (s_, r_) in keep.items():
                 sim.halo_set_buffers(d, s_.data_ptr(), r_.data_ptr(), cap)
             sim.rccl_comm_init(1, 0, sim.rccl_unique_id())
@@ -53,11 +55,11 @@ def main():
                 sim.add_agents(pts[group == g], StubHighLevelPlan((vx, scenes.WALK_SPEED * 0.2)), lp, 2.0)
             for _ in range(100):
                 sim.tile_step_rccl(0.05)
-            side.synchronize()
+            (sim.synchronize() if own else side.synchronize())
             t0 = time.perf_counter()
             for _ in range(steps):
                 sim.tile_step_rccl(0.05)
-            side.synchronize()
+            (sim.synchronize() if own else side.synchronize())
             el = time.perf_counter() - t0
             # the phases, in a pass of their own (event pairs cost the streams a few us each)
             sim.profile_reset()
@@ -65,13 +67,13 @@ def main():
             sim.profile_enable((1 << _abi.CS_K_COUNT) - 1)
             for _ in range(40):
                 sim.tile_step_rccl(0.05)
-            side.synchronize()
+            (sim.synchronize() if own else side.synchronize())
             sim.profile_enable(0)
             prof = sim.profile_read()
             print("   phases (us):", {k: round(1e3 * v["total_ms"] / v["launches"], 1) for k, v in prof.items() if v["launches"]}, flush=True)
             for _ in range(steps - 40):
                 sim.tile_step_rccl(0.05)
-            side.synchronize()
+            (sim.synchronize() if own else side.synchronize())
             out = sim.read_agents()
             stats = (sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD), sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD_USED))
             del sim
