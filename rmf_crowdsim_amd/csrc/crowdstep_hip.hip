@@ -151,21 +151,8 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   if (cfg && cfg->stream) {
     e->stream = (hipStream_t)cfg->stream;
   } else {
-    // CS_RESERVE_CUS=n (measurement, round 5): the engine's own stream leaves the last n compute units of the chip alone,
-    // so that the exchange of the overlapped schedule (RCCL's kernel on the second stream) finds a place to run while the
-    // step kernel's workgroups fill every other unit
-    const char* rv = getenv("CS_RESERVE_CUS");
-    const int reserve = rv ? atoi(rv) : 0;
-    hipDeviceProp_t pr;
-    if (reserve > 0 && hipGetDeviceProperties(&pr, e->device) == hipSuccess && reserve < pr.multiProcessorCount) {
-      const int n_cu = pr.multiProcessorCount;
-      std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-      for (int c = 0; c < n_cu - reserve; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-      if (hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
-        return create_failed(e, "hipExtStreamCreateWithCUMask failed");
-    } else if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
       return create_failed(e, "hipStreamCreate failed");
-    }
     e->own_stream = true;
   }
   hipDeviceProp_t prop;

@@ -567,6 +567,40 @@ def _rank_nccl_single(port, out_path):
                 stats = (sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD), sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD_USED))
                 del sim
             return out, stats
+        # The early-exchange form (round 5: ONE launch, the border windows first, the exchange behind k_wait_border) must
+        # send what the border windows PACKED, not what the buffers held before them: walkers march into the XLO band; in
+        # the step in which the first of them arrive there the border windows pack them and the exchange made ahead in
+        # that very call carries them to the peer (this rank): the received buffer must equal the send buffer, byte for
+        # byte, with a record count > 0, before anything unpacks it.
+        def early_exchange_carries_the_packed_records():
+            with torch.cuda.stream(side):
+                big = dict(width=240.0, height=420.0, cell_size=2.0, offset=(0.0, 0.0))
+                sim = Simulation(LocationHash2D(**big), device=0, stream=side.cuda_stream, tile=(10, 200, 0, 120),
+                                 halo_cells=1, flags=_abi.CS_CFG_TILE_OVERLAP, capacity_hint=140_000)
+                cap = 8192
+                keep = {d: (torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda"),
+                            torch.zeros((cap + 1) * RECORD, dtype=torch.uint8, device="cuda")) for d in (XLO, XHI)}
+                for d, (s_, r_) in keep.items():
+                    sim.halo_set_buffers(d, s_.data_ptr(), r_.data_ptr(), cap)
+                sim.rccl_comm_init(1, 0, sim.rccl_unique_id())
+                sim.halo_set_peers([0, 0, -1, -1, -1, -1, -1, -1])
+                lp = Zanlungo(*scenes.METRIC_ZANLUNGO)
+                pts = scenes.jittered_lattice(125_000, 0.6325, (26.0, 10.0), 0.2, 11, columns=560)
+                sim.add_agents(pts, StubHighLevelPlan((-scenes.WALK_SPEED, 0.0)), lp, 2.0)  # towards the XLO edge at x = 20
+                for k in range(80):
+                    sim.tile_step_rccl(0.05)
+                    side.synchronize()
+                    sent = keep[XLO][0].cpu().numpy()
+                    count = int(sent[:4].view("<u4")[0])
+                    if count > 0:
+                        got = keep[XLO][1].cpu().numpy()
+                        ahead = sim.kernel_stat(_abi.CS_STAT_EXCHANGES_AHEAD)
+                        same = sent[:(count + 1) * RECORD].tobytes() == got[:(count + 1) * RECORD].tobytes()
+                        print(f"early exchange: step {k}, {count} records packed by the border windows, received equal: {same}, "
+                              f"exchanges ahead so far {ahead}", flush=True)
+                        return same and count >= 50 and ahead >= k - 2
+                return False
+        early_carries = early_exchange_carries_the_packed_records()
         plain_big, plain_big_stats = middle_tile_125k(0)
         ahead_big, ahead_big_stats = middle_tile_125k(_abi.CS_CFG_TILE_OVERLAP)
         print("125k middle tile: exchanges ahead / used:", ahead_big_stats, "plain:", plain_big_stats, "same bits:",
@@ -577,6 +611,7 @@ def _rank_nccl_single(port, out_path):
                              np.isfinite(plain_big["x"]).all() and float(plain_big["y"].max()) > 164.0)
         checks = {"stream_order": ok, "mesh_engine_vs_torch": results["engine"].tobytes() == results["torch"].tobytes(),
                   "overlap_exchange_ahead": overlap_ahead, "overlap_exchange_ahead_at_configs2_tile_size": overlap_ahead_big,
+                  "early_exchange_carries_the_packed_records": early_carries,
                   "overlap_streams": results["overlap"].tobytes() == results["engine"].tobytes(),
                   "self_exchange_engine": recv_bytes["engine"], "self_exchange_torch": recv_bytes["torch"]}
         print("rccl checks:", checks, "records sent", sent, flush=True)
