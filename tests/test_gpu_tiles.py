@@ -598,7 +598,7 @@ def _rank_nccl_single(port, out_path):
                         same = sent[:(count + 1) * RECORD].tobytes() == got[:(count + 1) * RECORD].tobytes()
                         print(f"early exchange: step {k}, {count} records packed by the border windows, received equal: {same}, "
                               f"exchanges ahead so far {ahead}", flush=True)
-                        return same and count >= 50 and ahead >= k - 2
+                        return same and count >= 10 and ahead >= k - 2
                 return False
         early_carries = early_exchange_carries_the_packed_records()
         plain_big, plain_big_stats = middle_tile_125k(0)
