@@ -863,6 +863,9 @@ def run_leg(args, ctx, scaling, steps, warmup, clock_warmup_min, headline, overl
                 # agent: position, velocity, own preferred velocity, id, group) against the HBM peak
                 "hbm_read_frac": (agents_here * K4_READ_BYTES / (k4_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k4_ms > 0 else 0.0,
                 "hbm_read_target_frac": 0.40,
+                # the whole step (K1-K5 without spawn) against the same peak: SURVEY.md section 8(d)'s ~120 B per
+                # agent-step over the step's wall time
+                "whole_step_bytes_per_agent": 120, "whole_step_frac": agents_here * 120 / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS,
                 "kernel": "k_step_tiled" if args.kernel != "gather" else "k_step_gather",
                 "kernel_ms": k4_ms, "kernel_launches_timed": k4["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
