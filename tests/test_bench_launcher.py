@@ -108,6 +108,21 @@ def test_bench_gpus_2_with_the_overlap_as_the_headline_runs_the_plain_leg_first(
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_split_launches_at_configs2_size_equal_the_single_engine():
+    """The decomposition the overlapped schedule steps on (border windows as a launch of their own, CS_TILE_SPLIT=1) with
+    TWO RANKS at configs[2]'s full million agents, over the gloo host transport: after warm-up, timed region, report step
+    and per-phase pass the whole crowd of the mesh == one engine, bit for bit (--verify)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "1000000", "--steps", "10", "--warmup", "3",
+                        "--clock-warmup", "5", "--no-cpu-baseline", "--no-second-scaling-leg", "--no-overlap-ab", "--verify"],
+                       env=_env(CS_BENCH_BACKEND="gloo", CS_TILE_SPLIT="1"), capture_output=True, text=True, timeout=900)
+    line = _bench_line(p)
+    cfg = line["config"]
+    assert cfg["agents_total"] == 1_000_000 and cfg["verify"]["mesh_equals_single_engine"] is True
+    assert cfg["verify"]["agents"] == 1_000_000 and cfg["verify"]["steps_compared"] == 1 + 2 + 3 + 10 + 1 + 24
+    assert cfg["phase_us_rank0"].get("step_border", 0) > 0 and cfg["phase_us_rank0"].get("step_interior", 0) > 0
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_python_mesh_for_comparison():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--agents", "100000", "--steps", "5", "--warmup", "2",
                         "--clock-warmup", "3", "--no-cpu-baseline", "--mesh", "python", "--no-second-scaling-leg", "--no-overlap-ab"],
