@@ -399,7 +399,7 @@ def test_a_failing_step_of_the_distributed_form_is_agreed_on(monkeypatch):
         mesh.step(0.05, report=True)
 
 
-def _rank_failing(rank, world, port, out_path, layout=(2, 1)):
+def _rank_failing(rank, world, port, out_path, layout=(2, 1), second=False):
     import os
     import pickle
     import sys
@@ -414,6 +414,8 @@ def _rank_failing(rank, world, port, out_path, layout=(2, 1)):
         mesh = NativeTileMesh(LocationHash2D(**grid), layout, 1, device=0, rank=rank, n_ranks=world,
                               host_transport=TorchHostTransport(dist))
         _runaway_scene(mesh)   # the runaway lives on the last rank's tile (x >= 20, or >= 30)
+        if second:  # a second runaway, on the FIRST rank's tile, leaves over the top (y = 40) two steps after the first
+            mesh.add_agents([(5.0, 36.6)], StubHighLevelPlan((0.0, 4.0)), NoLocalPlan(), 2.0)
         raised = None
         for k in range(60):
             try:
@@ -458,12 +460,12 @@ def test_two_ranks_agree_on_a_failure_and_nobody_hangs(tmp_path):
     assert again0 == r0[1] and again1 == r1[1]
 
 
-def _failing_ranks(tmp_path, world, layout, port):
+def _failing_ranks(tmp_path, world, layout, port, second=False):
     import pickle
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = str(tmp_path / "failing")
-    procs = [ctx.Process(target=_rank_failing, args=(r, world, port, out, layout)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_failing, args=(r, world, port, out, layout, second)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -491,6 +493,20 @@ def test_ranks_agree_on_a_failure_through_the_halo_headers_alone(tmp_path, monke
     assert 14 < steps[0] <= 14 + layout[0] + layout[1]
     assert "Index out of bounds" in got[-1][0][1] and all("another rank" in g[0][1] for g in got[:-1])
     assert all(g[1] == g[0][1] for g in got)
+
+
+@pytest.mark.gpu
+def test_two_failures_on_two_ranks_within_the_agreement_window(tmp_path, monkeypatch):
+    """4 x 1 tiles, one rank each: the last tile fails in step 14, the first in step 17 (its runaway leaves over the top),
+    i.e. while the first failure's word is still on its way across the mesh.  The smallest word wins on every tile, so all
+    four ranks leave at the call the FIRST failure fixes, nobody issues an exchange the others will not take, both failing
+    ranks report the reference's error and the two in between "another rank"."""
+    monkeypatch.setenv("CS_MESH_CHECK_EVERY", "1000000")
+    got = _failing_ranks(tmp_path, 4, (4, 1), 29767, second=True)
+    steps = [g[0][0] for g in got]
+    assert all(g[0] is not None for g in got) and len(set(steps)) == 1 and 14 < steps[0] <= 14 + 5
+    assert "Index out of bounds" in got[3][0][1] and "Index out of bounds" in got[0][0][1]
+    assert "another rank" in got[1][0][1] and "another rank" in got[2][0][1]
 
 
 @pytest.mark.gpu
