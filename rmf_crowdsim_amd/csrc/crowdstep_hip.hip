@@ -159,19 +159,17 @@ cs_engine* cs_create(const cs_grid_desc* grid, const cs_device_cfg* cfg) {
   hipGetDeviceProperties(&prop, e->device);
   e->backend = std::string("hip:") + prop.gcnArchName;
   {
-    const void* kernels[8] = {reinterpret_cast<const void*>(k_step_tiled<false, false>), reinterpret_cast<const void*>(k_step_tiled<true, false>),
+    const void* kernels[6] = {reinterpret_cast<const void*>(k_step_tiled<false, false>), reinterpret_cast<const void*>(k_step_tiled<true, false>),
                               reinterpret_cast<const void*>(k_step_tiled<false, true>), reinterpret_cast<const void*>(k_step_tiled<true, true>),
                               reinterpret_cast<const void*>(k_step_tiled<false, false, true>),
-                              reinterpret_cast<const void*>(k_step_tiled<true, false, true>),
-                              reinterpret_cast<const void*>(k_step_tiled<false, true, true>),
-                              reinterpret_cast<const void*>(k_step_tiled<true, true, true>)};
-    for (int k = 0; k < 8; ++k) {
+                              reinterpret_cast<const void*>(k_step_tiled<true, false, true>)};
+    for (int k = 0; k < 6; ++k) {
       if (hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         (void)hipGetLastError();  // not fatal: the default 64 KiB covers the usual staged tile (wide cells need more)
       // static LDS of the tiled kernel: part of a workgroup's share of the CU's 160 KiB (the instantiations with builder
       // workgroups, k >= 2, carry the window builder's small arrays as well: priced for themselves)
       hipFuncAttributes fa;
-      uint32_t& slot = (k < 2 || k == 4 || k == 5) ? e->tile_static_lds : e->tile_static_lds_builders;
+      uint32_t& slot = (k < 2 || k >= 4) ? e->tile_static_lds : e->tile_static_lds_builders;
       if (hipFuncGetAttributes(&fa, kernels[k]) == hipSuccess && fa.sharedSizeBytes)
         slot = std::max(slot == 512u ? 0u : slot, (uint32_t)fa.sharedSizeBytes);
       (void)hipGetLastError();
